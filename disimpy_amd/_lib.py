@@ -1,0 +1,270 @@
+"""ctypes binding of the C ABI in include/dsim.h (libdsim_hip.so).
+
+There is no CPU fallback: if the HIP library is missing, or no AMD GPU is
+visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdsim_hip.so")
+
+# every symbol include/dsim.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "dsim_abi_version", "dsim_last_error", "dsim_device_count", "dsim_rng_init", "dsim_rng_init_device",
+    "dsim_create", "dsim_destroy", "dsim_set_positions", "dsim_set_rng_states", "dsim_set_mesh",
+    "dsim_run_free", "dsim_run_sphere", "dsim_run_cylinder", "dsim_run_ellipsoid", "dsim_run_mesh",
+    "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
+    "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
+    "dsim_last_run_ms", "dsim_set_tuning",
+)  # fmt: skip
+
+_f64p = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_h = C.c_void_p
+
+_lib = None
+
+
+class DsimError(RuntimeError):
+    """A call into libdsim_hip.so failed."""
+
+
+def load():
+    """Load libdsim_hip.so (built by ``__graft_entry__.build()`` / ``make -C disimpy_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsimError(
+            "HIP extension %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C disimpy_amd/csrc` (there is no CPU fallback)" % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.dsim_last_error.restype = C.c_char_p
+    lib.dsim_rng_init.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
+    lib.dsim_rng_init_device.argtypes = [_h, C.c_uint64]
+    lib.dsim_create.argtypes = [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _f64p, _f64p,
+                                _f64p, C.c_double, C.c_double]
+    lib.dsim_destroy.argtypes = [_h]
+    lib.dsim_set_positions.argtypes = [_h, _f64p]
+    lib.dsim_set_rng_states.argtypes = [_h, _u64p]
+    lib.dsim_set_mesh.argtypes = [_h, _f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p,
+                                  C.c_int64]
+    lib.dsim_run_free.argtypes = [_h, C.c_int32, C.c_int32]
+    lib.dsim_run_sphere.argtypes = [_h, C.c_double, C.c_int64, C.c_double, C.c_int32, C.c_int32]
+    lib.dsim_run_cylinder.argtypes = [_h, C.c_double, _f64p, _f64p, C.c_int64, C.c_double, C.c_int32, C.c_int32]
+    lib.dsim_run_ellipsoid.argtypes = [_h, _f64p, _f64p, _f64p, C.c_int64, C.c_double, C.c_int32, C.c_int32]
+    lib.dsim_run_mesh.argtypes = [_h, C.c_int64, C.c_double, C.c_double, C.c_int32, C.c_int32]
+    lib.dsim_get_signal.argtypes = [_h, _f64p, _f64p, _i64p]
+    lib.dsim_get_positions.argtypes = [_h, _f64p]
+    lib.dsim_get_phases.argtypes = [_h, _f64p]
+    lib.dsim_get_iter_exc.argtypes = [_h, _u8p]
+    lib.dsim_get_rng_states.argtypes = [_h, _u64p]
+    lib.dsim_fill_mesh.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_uint64, _f64p, C.c_int64, _i64p, C.c_int64,
+                                   _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, _f64p]
+    lib.dsim_mesh_subdivide.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p,
+                                        _i64p]
+    lib.dsim_triangle_box_overlap.argtypes = [_f64p, _f64p]
+    lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
+    lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
+    lib.dsim_set_tuning.argtypes = [_h, C.c_int32, C.c_int32, C.c_int32]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DsimError("libdsim_hip: %s (code %d)" % (load().dsim_last_error().decode(), rc))
+
+
+def device_count():
+    return int(load().dsim_device_count())
+
+
+def _c(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def p_f64(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def p_i64(a):
+    return a.ctypes.data_as(_i64p)
+
+
+def p_u64(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def rng_init(seed, first_index, n):
+    """create_xoroshiro128p_states restated on the host: (n, 2) uint64 of {s0, s1}."""
+    out = np.zeros((n, 2), dtype=np.uint64)
+    check(load().dsim_rng_init(seed, first_index, n, p_u64(out)))
+    return out
+
+
+def mesh_subdivide(vertices, faces, xs, ys, zs, n_sv):
+    """substrates._mesh_space_subdivision in C: returns (triangle_indices, subvoxel_indices) int64."""
+    lib = load()
+    v = _c(vertices, np.float64)
+    f = _c(faces, np.int64)
+    xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+    nsv = _c(n_sv, np.int64)
+    n_sub = int(np.prod(nsv))
+    svi = np.zeros((n_sub, 2), dtype=np.int64)
+    n_refs = C.c_int64(0)
+    check(lib.dsim_mesh_subdivide(p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv),
+                                  p_i64(svi), None, C.byref(n_refs)))
+    tri = np.zeros(max(n_refs.value, 0), dtype=np.int64)
+    check(lib.dsim_mesh_subdivide(p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv),
+                                  p_i64(svi), p_i64(tri) if len(tri) else None, C.byref(n_refs)))
+    return tri, svi
+
+
+def triangle_box_overlap(triangle, box):
+    t, b = _c(triangle, np.float64), _c(box, np.float64)
+    rc = load().dsim_triangle_box_overlap(p_f64(t), p_f64(b))
+    if rc < 0:
+        check(rc)
+    return bool(rc)
+
+
+def interval_sv_overlap(xs, x1, x2):
+    xs = _c(xs, np.float64)
+    ll, ul = C.c_int64(0), C.c_int64(0)
+    check(load().dsim_interval_sv_overlap(p_f64(xs), len(xs), x1, x2, C.byref(ll), C.byref(ul)))
+    return ll.value, ul.value
+
+
+class Sim:
+    """Owner of one ``dsim_handle`` (one walker shard on one GPU)."""
+
+    def __init__(self, n_walkers, gradient, dt, step_l, device=0, first_walker=0):
+        lib = load()
+        if lib.dsim_device_count() <= 0:
+            raise DsimError("no HIP device visible (need an AMD GPU with ROCm); there is no CPU fallback")
+        g = np.asarray(gradient, dtype=np.float64)
+        self.M, self.T = int(g.shape[0]), int(g.shape[1])
+        self.n = int(n_walkers)
+        gx, gy, gz = (np.ascontiguousarray(g[:, :, k]) for k in range(3))
+        self._h = _h()
+        check(lib.dsim_create(C.byref(self._h), device, self.n, first_walker, self.M, self.T, p_f64(gx), p_f64(gy),
+                              p_f64(gz), dt, step_l))
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # state ------------------------------------------------------------------
+    def set_positions(self, pos):
+        pos = _c(pos, np.float64)
+        assert pos.shape == (self.n, 3)
+        check(self._lib.dsim_set_positions(self._h, p_f64(pos)))
+
+    def set_rng_states(self, states):
+        st = _c(states, np.uint64)
+        assert st.shape == (self.n, 2)
+        check(self._lib.dsim_set_rng_states(self._h, p_u64(st)))
+
+    def rng_init_device(self, seed):
+        check(self._lib.dsim_rng_init_device(self._h, seed))
+
+    def set_mesh(self, vertices, faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices):
+        v, f = _c(vertices, np.float64), _c(faces, np.int64)
+        xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+        nsv = _c(n_sv, np.int64)
+        svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
+        check(self._lib.dsim_set_mesh(self._h, p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs),
+                                      p_i64(nsv), p_i64(svi), p_i64(tri), len(tri)))
+
+    def set_tuning(self, block_size=0, tile_steps=0, meas_per_pass=0):
+        check(self._lib.dsim_set_tuning(self._h, block_size, tile_steps, meas_per_pass))
+
+    # time loop ----------------------------------------------------------------
+    def run_free(self, t0, t1):
+        check(self._lib.dsim_run_free(self._h, t0, t1))
+
+    def run_sphere(self, radius, max_iter, epsilon, t0, t1):
+        check(self._lib.dsim_run_sphere(self._h, radius, max_iter, epsilon, t0, t1))
+
+    def run_cylinder(self, radius, R, R_inv, max_iter, epsilon, t0, t1):
+        R, R_inv = _c(R, np.float64), _c(R_inv, np.float64)
+        check(self._lib.dsim_run_cylinder(self._h, radius, p_f64(R), p_f64(R_inv), max_iter, epsilon, t0, t1))
+
+    def run_ellipsoid(self, semiaxes, R, R_inv, max_iter, epsilon, t0, t1):
+        ax, R, R_inv = _c(semiaxes, np.float64), _c(R, np.float64), _c(R_inv, np.float64)
+        check(self._lib.dsim_run_ellipsoid(self._h, p_f64(ax), p_f64(R), p_f64(R_inv), max_iter, epsilon, t0, t1))
+
+    def run_mesh(self, max_iter, epsilon, perm_prob, t0, t1):
+        check(self._lib.dsim_run_mesh(self._h, max_iter, epsilon, float(perm_prob), t0, t1))
+
+    def last_run_ms(self):
+        ms, nl = C.c_double(0), C.c_int32(0)
+        check(self._lib.dsim_last_run_ms(self._h, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    # outputs ------------------------------------------------------------------
+    def signal(self):
+        c, s = np.zeros(self.M), np.zeros(self.M)
+        nexc = C.c_int64(0)
+        check(self._lib.dsim_get_signal(self._h, p_f64(c), p_f64(s), C.byref(nexc)))
+        return c, s, nexc.value
+
+    def positions(self):
+        out = np.zeros((self.n, 3))
+        check(self._lib.dsim_get_positions(self._h, p_f64(out)))
+        return out
+
+    def phases(self):
+        out = np.zeros((self.M, self.n))
+        check(self._lib.dsim_get_phases(self._h, p_f64(out)))
+        return out
+
+    def iter_exc(self):
+        out = np.zeros(self.n, dtype=np.uint8)
+        check(self._lib.dsim_get_iter_exc(self._h, out.ctypes.data_as(_u8p)))
+        return out.astype(bool)
+
+    def rng_states(self):
+        out = np.zeros((self.n, 2), dtype=np.uint64)
+        check(self._lib.dsim_get_rng_states(self._h, p_u64(out)))
+        return out
+
+
+def fill_mesh(n_points, intra, seed, vertices, faces, voxel_size, xs, ys, zs, n_sv, subvoxel_indices,
+              triangle_indices, device=0):
+    lib = load()
+    if lib.dsim_device_count() <= 0:
+        raise DsimError("no HIP device visible (need an AMD GPU with ROCm); there is no CPU fallback")
+    v, f = _c(vertices, np.float64), _c(faces, np.int64)
+    vs = _c(voxel_size, np.float64)
+    xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+    nsv = _c(n_sv, np.int64)
+    svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
+    out = np.zeros((n_points, 3))
+    check(lib.dsim_fill_mesh(device, n_points, int(bool(intra)), seed, p_f64(v), len(v), p_i64(f), len(f), p_f64(vs),
+                             p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri), len(tri),
+                             p_f64(out)))
+    return out

@@ -1,0 +1,225 @@
+/* dsim_device.h - per-walker device functions of the random-walk step (gfx950).
+ *
+ * Register-resident restatement of disimpy/simulations.py:23-343, :616-679 and
+ * numba/cuda/random.py:79-98, :128-167, :199-221.  Walker state lives in
+ * scalars (SoA in HBM, registers inside the fused time loop); there are no
+ * per-thread arrays in global memory as in the reference.
+ *
+ * Arithmetic convention (must match oracle/dsim_oracle.c so that the two agree
+ * bit for bit; this TU is compiled with -ffp-contract=off):
+ *      a*b + c*d + e*f  ->  fma(e, f, fma(a, b, c*d))
+ *      a*b - c*d        ->  fma(a, b, -(c*d))
+ *      x - y*z          ->  fma(-y, z, x)
+ */
+#ifndef DSIM_DEVICE_H
+#define DSIM_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsim_math.h"
+
+#define DSD __device__ __forceinline__
+
+struct V3 {
+  double x, y, z;
+};
+
+struct Rng {
+  uint64_t s0, s1;
+};
+
+DSD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* numba/cuda/random.py:79-98 */
+DSD uint64_t rng_next(Rng &r) {
+  uint64_t s0 = r.s0, s1 = r.s1;
+  uint64_t result = s0 + s1;
+  s1 ^= s0;
+  r.s0 = rotl64(s0, 55) ^ s1 ^ (s1 << 14);
+  r.s1 = rotl64(s1, 36);
+  return result;
+}
+
+/* numba/cuda/random.py:128-139 */
+DSD double u64_to_unit_f64(uint64_t x) { return (double)(x >> 11) * 0x1p-53; }
+DSD double rng_uniform_f64(Rng &r) { return u64_to_unit_f64(rng_next(r)); }
+DSD float rng_uniform_f32(Rng &r) { return (float)u64_to_unit_f64(rng_next(r)); }
+
+/* numba/cuda/random.py:199-221: float32 uniforms, float32 log, float64 rest */
+DSD double rng_normal_f64(Rng &r, const double *log_tab) {
+  float u1 = rng_uniform_f32(r);
+  float u2 = rng_uniform_f32(r);
+  double lg = (double)ds_logf(u1, log_tab);
+  return __builtin_sqrt(-2.0 * lg) * ds_cos_0_2pi(6.283185307179586 * (double)u2);
+}
+
+/* simulations.py:23-36 */
+DSD double dot3(const V3 &a, const V3 &b) { return __builtin_fma(a.z, b.z, __builtin_fma(a.x, b.x, a.y * b.y)); }
+
+/* simulations.py:39-56 */
+DSD V3 cross3(const V3 &a, const V3 &b) {
+  V3 c;
+  c.x = __builtin_fma(a.y, b.z, -(a.z * b.y));
+  c.y = __builtin_fma(a.z, b.x, -(a.x * b.z));
+  c.z = __builtin_fma(a.x, b.y, -(a.y * b.x));
+  return c;
+}
+
+/* simulations.py:59-74 (three divides, not a reciprocal) */
+DSD void normalize3(V3 &v) {
+  double length = __builtin_sqrt(dot3(v, v));
+  v.x = v.x / length;
+  v.y = v.y / length;
+  v.z = v.z / length;
+}
+
+/* simulations.py:121-138 */
+DSD V3 random_step(Rng &r, const double *log_tab) {
+  V3 s;
+  s.x = rng_normal_f64(r, log_tab);
+  s.y = rng_normal_f64(r, log_tab);
+  s.z = rng_normal_f64(r, log_tab);
+  normalize3(s);
+  return s;
+}
+
+/* simulations.py:141-160, R row-major */
+DSD V3 mat_mul(const double *R, const V3 &v) {
+  V3 o;
+  o.x = __builtin_fma(R[2], v.z, __builtin_fma(R[0], v.x, R[1] * v.y));
+  o.y = __builtin_fma(R[5], v.z, __builtin_fma(R[3], v.x, R[4] * v.y));
+  o.z = __builtin_fma(R[8], v.z, __builtin_fma(R[6], v.x, R[7] * v.y));
+  return o;
+}
+
+/* simulations.py:163-182 on the (y, z) components */
+DSD double line_circle_intersection(double r0, double r1, double s0, double s1, double radius) {
+  double A = __builtin_fma(s0, s0, s1 * s1);
+  double B = 2 * __builtin_fma(r0, s0, r1 * s1);
+  double C = __builtin_fma(-radius, radius, __builtin_fma(r0, r0, r1 * r1));
+  return (-B + __builtin_sqrt(__builtin_fma(B, B, -(4 * A * C)))) / (2 * A);
+}
+
+/* simulations.py:185-202 */
+DSD double line_sphere_intersection(const V3 &r0, const V3 &step, double radius) {
+  double dp = dot3(step, r0);
+  double inner = __builtin_fma(-radius, radius, dot3(r0, r0));
+  return -dp + __builtin_sqrt(__builtin_fma(dp, dp, -inner));
+}
+
+/* simulations.py:205-231 */
+DSD double line_ellipsoid_intersection(const V3 &r0, const V3 &step, double a, double b, double c) {
+  double sa = step.x / a, sb = step.y / b, sc = step.z / c;
+  double A = __builtin_fma(sc, sc, __builtin_fma(sa, sa, sb * sb));
+  double ia = 1.0 / (a * a), ib = 1.0 / (b * b), ic = 1.0 / (c * c);
+  double B = 2 * __builtin_fma(ic * step.z, r0.z, __builtin_fma(ia * step.x, r0.x, ib * step.y * r0.y));
+  double ra = r0.x / a, rb = r0.y / b, rc = r0.z / c;
+  double C = __builtin_fma(rc, rc, __builtin_fma(ra, ra, rb * rb)) - 1;
+  return (-B + __builtin_sqrt(__builtin_fma(B, B, -(4 * A * C)))) / (2 * A);
+}
+
+/* simulations.py:234-275 on a pre-gathered record {A, E1 = B - A, E2 = C - A}
+ * (the subtractions are done once on the host in the same IEEE arithmetic). */
+DSD double ray_triangle_intersection_check(const V3 &A, const V3 &E1, const V3 &E2, const V3 &r0, const V3 &step) {
+  V3 T = {r0.x - A.x, r0.y - A.y, r0.z - A.z};
+  V3 P = cross3(step, E2);
+  V3 Q = cross3(T, E1);
+  double det = dot3(P, E1);
+  if (det != 0) {
+    double inv = 1 / det;
+    double t = inv * dot3(Q, E2);
+    double u = inv * dot3(P, T);
+    double v = inv * dot3(Q, step);
+    if (u >= 0 && u <= 1 && v >= 0 && v <= 1 && u + v <= 1) return t;
+    return DS_NAN;
+  }
+  return DS_NAN;
+}
+
+/* simulations.py:278-311; updates r0, step and the (possibly flipped) normal */
+DSD void reflection(V3 &r0, V3 &step, double d, V3 &n, double epsilon) {
+  V3 is = {__builtin_fma(d, step.x, r0.x), __builtin_fma(d, step.y, r0.y), __builtin_fma(d, step.z, r0.z)};
+  V3 v = {is.x - r0.x, is.y - r0.y, is.z - r0.z};
+  double dp = dot3(v, n);
+  if (dp > 0) {
+    n.x = -n.x;
+    n.y = -n.y;
+    n.z = -n.z;
+    dp = dot3(v, n);
+  }
+  double m2dp = -(2 * dp);
+  step.x = (__builtin_fma(m2dp, n.x, v.x) + is.x) - is.x;
+  step.y = (__builtin_fma(m2dp, n.y, v.y) + is.y) - is.y;
+  step.z = (__builtin_fma(m2dp, n.z, v.z) + is.z) - is.z;
+  normalize3(step);
+  r0.x = __builtin_fma(epsilon, n.x, is.x);
+  r0.y = __builtin_fma(epsilon, n.y, is.y);
+  r0.z = __builtin_fma(epsilon, n.z, is.z);
+}
+
+/* simulations.py:314-343 */
+DSD void crossing(V3 &r0, const V3 &step, double d, V3 &n, double epsilon) {
+  V3 is = {__builtin_fma(d, step.x, r0.x), __builtin_fma(d, step.y, r0.y), __builtin_fma(d, step.z, r0.z)};
+  V3 v = {is.x - r0.x, is.y - r0.y, is.z - r0.z};
+  double dp = dot3(v, n);
+  if (dp < 0) {
+    n.x = -n.x;
+    n.y = -n.y;
+    n.z = -n.z;
+  }
+  r0.x = __builtin_fma(epsilon, n.x, is.x);
+  r0.y = __builtin_fma(epsilon, n.y, is.y);
+  r0.z = __builtin_fma(epsilon, n.z, is.z);
+}
+
+/* Subvoxel lookups.  The reference scans the boundary array linearly
+ * (simulations.py:616-651); the boundaries are np.linspace(0, L, n+1)
+ * (substrates.py:506-508), so a multiply gives a first guess that is then
+ * corrected against the ACTUAL boundary values, reproducing the reference's
+ * strict/non-strict comparisons exactly.  xs points at n+1 doubles in LDS. */
+DSD int ll_subvoxel_overlap(const double *xs, int n, double inv_h, double xmin) {
+  if (xmin <= xs[0]) return 0;
+  if (xmin >= xs[n]) return n;
+  int i = (int)(xmin * inv_h);
+  i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+  while (xs[i] > xmin) --i;      /* largest i with xs[i] <= xmin ... */
+  while (xs[i + 1] <= xmin) ++i; /* ... = (first i with xs[i] > xmin) - 1 */
+  return i;
+}
+
+DSD int ul_subvoxel_overlap(const double *xs, int n, double inv_h, double xmax) {
+  if (xmax != xmax) return 0; /* NaN: the reference's scan stops at i = 0 */
+  if (xmax >= xs[n]) return n;
+  if (xmax <= xs[0]) return 0;
+  int i = (int)(xmax * inv_h) + 1;
+  i = i < 1 ? 1 : (i > n ? n : i);
+  while (xs[i - 1] >= xmax) --i; /* smallest i with xs[i] >= xmax */
+  while (xs[i] < xmax) ++i;
+  return i;
+}
+
+/* simulations.py:654-679 */
+DSD int ll_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, double x1, double x2) {
+  double xmin = x1 < x2 ? x1 : x2;
+  double voxel = __builtin_fabs(xs[n] - xs[0]);
+  double k = __builtin_floor(xmin / voxel);
+  double shifted = __builtin_fma(-k, voxel, xmin);
+  return ll_subvoxel_overlap(xs, n, inv_h, shifted) + (int)k * n;
+}
+
+DSD int ul_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, double x1, double x2) {
+  double xmax = x1 > x2 ? x1 : x2;
+  double voxel = __builtin_fabs(xs[n] - xs[0]);
+  double k = __builtin_floor(xmax / voxel);
+  double shifted = __builtin_fma(-k, voxel, xmax);
+  return ul_subvoxel_overlap(xs, n, inv_h, shifted) + (int)k * n;
+}
+
+/* floor division for the periodic image index (Python: math.floor(x / n)) */
+DSD int floor_div(int x, int n) {
+  int q = x / n;
+  return (x % n != 0 && ((x < 0) != (n < 0))) ? q - 1 : q;
+}
+
+#endif /* DSIM_DEVICE_H */

@@ -1,0 +1,974 @@
+/* dsim_hip.hip - host side of the C ABI declared in include/dsim.h.
+ *
+ * Owns device memory (SoA walker state, phases, gradient tiles, compact mesh
+ * index), one HIP stream per simulation and the launch logic.  Compiled for
+ * gfx950 only, with -ffp-contract=off (see dsim_device.h).
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/dsim.h"
+#include "dsim_kernels.h"
+
+#define DSIM_GAMMA 267.513e6 /* gradients.py:13 */
+
+/* ------------------------------------------------------------------ errors --- */
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(DSIM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char *dsim_last_error(void) { return g_err.c_str(); }
+extern "C" int dsim_abi_version(void) { return 1; }
+
+extern "C" int dsim_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+/* ----------------------------------------------------------------- RNG (host) --- */
+
+struct HostRng {
+  uint64_t s0, s1;
+};
+
+static inline uint64_t h_rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* numba/cuda/random.py:79-98 */
+static inline uint64_t h_next(HostRng &r) {
+  uint64_t s0 = r.s0, s1 = r.s1, res = s0 + s1;
+  s1 ^= s0;
+  r.s0 = h_rotl(s0, 55) ^ s1 ^ (s1 << 14);
+  r.s1 = h_rotl(s1, 36);
+  return res;
+}
+
+/* numba/cuda/random.py:101-125 */
+static void h_jump(HostRng &r) {
+  static const uint64_t J[2] = {0xbeac0467eba5facbULL, 0xd86b048b86aa9922ULL};
+  uint64_t a = 0, c = 0;
+  for (int i = 0; i < 2; i++)
+    for (int b = 0; b < 64; b++) {
+      if (J[i] & (1ULL << b)) {
+        a ^= r.s0;
+        c ^= r.s1;
+      }
+      h_next(r);
+    }
+  r.s0 = a;
+  r.s1 = c;
+}
+
+/* numba/cuda/random.py:45-68 */
+static HostRng h_seed_state(uint64_t seed) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  HostRng r = {z, z};
+  return r;
+}
+
+/* The xoroshiro128+ state transition is linear over GF(2), so "jump 2^64 draws"
+ * is a 128x128 bit matrix; column b is the image of basis vector e_b.  Level k
+ * holds the matrix of 2^k jumps, which lets any state index be reached with
+ * popcount(index) matrix-vector products instead of `index` sequential jumps
+ * (numba/cuda/random.py:224-240 is sequential). */
+struct JumpTables {
+  std::vector<HostRng> cols; /* [levels][128] */
+  int levels = 0;
+};
+
+static HostRng matvec(const HostRng *cols, HostRng v) {
+  HostRng o = {0, 0};
+  for (int b = 0; b < 64; b++)
+    if (v.s0 >> b & 1) {
+      o.s0 ^= cols[b].s0;
+      o.s1 ^= cols[b].s1;
+    }
+  for (int b = 0; b < 64; b++)
+    if (v.s1 >> b & 1) {
+      o.s0 ^= cols[64 + b].s0;
+      o.s1 ^= cols[64 + b].s1;
+    }
+  return o;
+}
+
+static const JumpTables &jump_tables() {
+  static JumpTables jt;
+  if (jt.levels) return jt;
+  const int L = 48;
+  jt.cols.resize((size_t)L * 128);
+  /* level 0: apply the reference's jump() to each basis vector */
+  for (int b = 0; b < 128; b++) {
+    HostRng e = {b < 64 ? 1ULL << b : 0, b >= 64 ? 1ULL << (b - 64) : 0};
+    h_jump(e);
+    jt.cols[b] = e;
+  }
+  for (int k = 1; k < L; k++)
+    for (int b = 0; b < 128; b++) jt.cols[(size_t)k * 128 + b] = matvec(&jt.cols[(size_t)(k - 1) * 128], jt.cols[(size_t)(k - 1) * 128 + b]);
+  jt.levels = L;
+  return jt;
+}
+
+static HostRng h_state_at(uint64_t seed, uint64_t index) {
+  const JumpTables &jt = jump_tables();
+  HostRng r = h_seed_state(seed);
+  for (int k = 0; k < jt.levels && (index >> k); k++)
+    if (index >> k & 1) r = matvec(&jt.cols[(size_t)k * 128], r);
+  return r;
+}
+
+extern "C" int dsim_rng_init(uint64_t seed, uint64_t first_index, uint64_t n, uint64_t *out) {
+  if (!out && n) return fail(DSIM_ERR_INVALID, "dsim_rng_init: out is NULL");
+  if (n == 0) return DSIM_OK;
+  if ((first_index + n) >> 47) return fail(DSIM_ERR_INVALID, "dsim_rng_init: index range too large");
+  /* first state through the jump matrices, the rest by the reference's own
+   * sequential recurrence state[i] = jump(state[i-1]) */
+  HostRng r = h_state_at(seed, first_index);
+  for (uint64_t i = 0; i < n; i++) {
+    out[2 * i] = r.s0;
+    out[2 * i + 1] = r.s1;
+    if (i + 1 < n) h_jump(r);
+  }
+  return DSIM_OK;
+}
+
+/* device-side parallel seeding */
+__global__ void rng_init_kernel(uint64_t seed_s0, uint64_t seed_s1, uint64_t first, int64_t n, const uint64_t *cols,
+                                int levels, uint64_t *s0, uint64_t *s1) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t idx = first + (uint64_t)i;
+  uint64_t a = seed_s0, c = seed_s1;
+  for (int k = 0; k < levels && (idx >> k); k++) {
+    if (!(idx >> k & 1)) continue;
+    const uint64_t *m = cols + (size_t)k * 256;
+    uint64_t na = 0, nc = 0;
+    for (int b = 0; b < 64; b++) {
+      uint64_t mask = 0 - (a >> b & 1);
+      na ^= m[2 * b] & mask;
+      nc ^= m[2 * b + 1] & mask;
+    }
+    for (int b = 0; b < 64; b++) {
+      uint64_t mask = 0 - (c >> b & 1);
+      na ^= m[128 + 2 * b] & mask;
+      nc ^= m[128 + 2 * b + 1] & mask;
+    }
+    a = na;
+    c = nc;
+  }
+  s0[i] = a;
+  s1[i] = c;
+}
+
+/* ------------------------------------------------------------------ handle --- */
+
+struct DevMesh {
+  double *tri = nullptr;
+  int2 *sv_range = nullptr;
+  int32_t *tri_idx = nullptr;
+  double *bounds = nullptr;
+  int nx = 0, ny = 0, nz = 0;
+  double inv_h[3] = {0, 0, 0};
+  bool set = false;
+};
+
+struct dsim_sim {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int64_t n = 0, first = 0;
+  int M = 0, T = 0;
+  double dt = 0, step_l = 0;
+  double *x[2] = {nullptr, nullptr}, *y[2] = {nullptr, nullptr}, *z[2] = {nullptr, nullptr};
+  uint64_t *s0[2] = {nullptr, nullptr}, *s1[2] = {nullptr, nullptr};
+  int cur = 0; /* which of the two state buffers is current */
+  double *phase = nullptr;
+  uint8_t *exc = nullptr;
+  double *g4 = nullptr;
+  double *partial = nullptr, *sig_out = nullptr;
+  int sig_blocks = 0;
+  void *staging = nullptr;
+  size_t staging_bytes = 0;
+  DevMesh mesh;
+  double last_ms = 0;
+  int last_launches = 0;
+  int block_size = 256, tile_steps = 0, meas_per_pass = 0;
+};
+
+static void free_mesh(DevMesh &m) {
+  if (m.tri) (void)hipFree(m.tri);
+  if (m.sv_range) (void)hipFree(m.sv_range);
+  if (m.tri_idx) (void)hipFree(m.tri_idx);
+  if (m.bounds) (void)hipFree(m.bounds);
+  m = DevMesh();
+}
+
+static int ensure_staging(dsim_sim *h, size_t bytes) {
+  if (h->staging_bytes >= bytes) return DSIM_OK;
+  if (h->staging) (void)hipFree(h->staging);
+  h->staging = nullptr;
+  h->staging_bytes = 0;
+  HIP_TRY(hipMalloc(&h->staging, bytes));
+  h->staging_bytes = bytes;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_destroy(dsim_handle h) {
+  if (!h) return DSIM_OK;
+  (void)hipSetDevice(h->device);
+  for (int b = 0; b < 2; b++) {
+    if (h->x[b]) (void)hipFree(h->x[b]);
+    if (h->y[b]) (void)hipFree(h->y[b]);
+    if (h->z[b]) (void)hipFree(h->z[b]);
+    if (h->s0[b]) (void)hipFree(h->s0[b]);
+    if (h->s1[b]) (void)hipFree(h->s1[b]);
+  }
+  if (h->phase) (void)hipFree(h->phase);
+  if (h->exc) (void)hipFree(h->exc);
+  if (h->g4) (void)hipFree(h->g4);
+  if (h->partial) (void)hipFree(h->partial);
+  if (h->sig_out) (void)hipFree(h->sig_out);
+  if (h->staging) (void)hipFree(h->staging);
+  free_mesh(h->mesh);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return DSIM_OK;
+}
+
+static int create_impl(dsim_sim *h, const double *gx, const double *gy, const double *gz) {
+  const int64_t n = h->n;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  for (int b = 0; b < 2; b++) {
+    HIP_TRY(hipMalloc(&h->x[b], n * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->y[b], n * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->z[b], n * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->s0[b], n * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&h->s1[b], n * sizeof(uint64_t)));
+  }
+  HIP_TRY(hipMalloc(&h->phase, (size_t)h->M * n * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->exc, n));
+  HIP_TRY(hipMemsetAsync(h->x[0], 0, n * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->y[0], 0, n * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->z[0], 0, n * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->s0[0], 0, n * sizeof(uint64_t), h->stream));
+  HIP_TRY(hipMemsetAsync(h->s1[0], 0, n * sizeof(uint64_t), h->stream));
+  HIP_TRY(hipMemsetAsync(h->phase, 0, (size_t)h->M * n * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->exc, 0, n, h->stream));
+  /* gradient re-laid-out [t][m][gx gy gz 0]: one contiguous, 16-byte aligned LDS tile per range of steps */
+  std::vector<double> g4((size_t)h->T * h->M * 4);
+  for (int m = 0; m < h->M; m++)
+    for (int t = 0; t < h->T; t++) {
+      size_t o = ((size_t)t * h->M + m) * 4;
+      g4[o] = gx[(size_t)m * h->T + t];
+      g4[o + 1] = gy[(size_t)m * h->T + t];
+      g4[o + 2] = gz[(size_t)m * h->T + t];
+      g4[o + 3] = 0.0;
+    }
+  HIP_TRY(hipMalloc(&h->g4, g4.size() * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(h->g4, g4.data(), g4.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->sig_blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+  HIP_TRY(hipMalloc(&h->partial, (size_t)h->M * h->sig_blocks * 2 * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->sig_out, (size_t)(2 * h->M + 1) * sizeof(double)));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int64_t first_walker, int32_t M, int32_t T,
+                           const double *gx, const double *gy, const double *gz, double dt, double step_l) {
+  if (!out) return fail(DSIM_ERR_INVALID, "dsim_create: out is NULL");
+  *out = nullptr;
+  if (n_walkers <= 0 || first_walker < 0) return fail(DSIM_ERR_INVALID, "dsim_create: bad walker range");
+  if (M <= 0 || T <= 0 || !gx || !gy || !gz) return fail(DSIM_ERR_INVALID, "dsim_create: bad gradient");
+  if (!(dt > 0) || !(step_l >= 0)) return fail(DSIM_ERR_INVALID, "dsim_create: bad dt / step_l");
+  int ndev = dsim_device_count();
+  if (ndev <= 0) return fail(DSIM_ERR_NO_DEVICE, "no HIP device visible (need an AMD GPU with ROCm)");
+  if (device < 0 || device >= ndev) return fail(DSIM_ERR_INVALID, "dsim_create: device %d out of range (%d)", device, ndev);
+  dsim_sim *h = new dsim_sim();
+  h->device = device;
+  h->n = n_walkers;
+  h->first = first_walker;
+  h->M = M;
+  h->T = T;
+  h->dt = dt;
+  h->step_l = step_l;
+  int rc = create_impl(h, gx, gy, gz);
+  if (rc != DSIM_OK) {
+    std::string keep = g_err;
+    dsim_destroy(h);
+    g_err = keep;
+    return rc;
+  }
+  *out = h;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (block_size) {
+    if (block_size < 64 || block_size > 256 || block_size % 64) return fail(DSIM_ERR_INVALID, "block_size must be 64, 128, 192 or 256");
+    h->block_size = block_size;
+  }
+  if (tile_steps > 0) h->tile_steps = tile_steps;
+  if (meas_per_pass > 0) h->meas_per_pass = meas_per_pass;
+  return DSIM_OK;
+}
+
+static inline int grid_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
+  if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_set_positions: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_staging(h, (size_t)h->n * 3 * sizeof(double));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->staging, pos, (size_t)h->n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  aos_to_soa_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>((const double *)h->staging, h->n, h->x[h->cur], h->y[h->cur], h->z[h->cur]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_positions(dsim_handle h, double *pos) {
+  if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_get_positions: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_staging(h, (size_t)h->n * 3 * sizeof(double));
+  if (rc) return rc;
+  soa_to_aos_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->x[h->cur], h->y[h->cur], h->z[h->cur], h->n, (double *)h->staging);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pos, h->staging, (size_t)h->n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_set_rng_states(dsim_handle h, const uint64_t *st) {
+  if (!h || !st) return fail(DSIM_ERR_INVALID, "dsim_set_rng_states: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_staging(h, (size_t)h->n * 2 * sizeof(uint64_t));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->staging, st, (size_t)h->n * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  states_to_soa_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>((const uint64_t *)h->staging, h->n, h->s0[h->cur], h->s1[h->cur]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_rng_states(dsim_handle h, uint64_t *st) {
+  if (!h || !st) return fail(DSIM_ERR_INVALID, "dsim_get_rng_states: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_staging(h, (size_t)h->n * 2 * sizeof(uint64_t));
+  if (rc) return rc;
+  soa_to_states_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->s0[h->cur], h->s1[h->cur], h->n, (uint64_t *)h->staging);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(st, h->staging, (size_t)h->n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_rng_init_device(dsim_handle h, uint64_t seed) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (((uint64_t)h->first + (uint64_t)h->n) >> 47) return fail(DSIM_ERR_INVALID, "walker index range too large");
+  HIP_TRY(hipSetDevice(h->device));
+  const JumpTables &jt = jump_tables();
+  size_t bytes = jt.cols.size() * sizeof(HostRng);
+  int rc = ensure_staging(h, bytes);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->staging, jt.cols.data(), bytes, hipMemcpyHostToDevice, h->stream));
+  HostRng s = h_seed_state(seed);
+  rng_init_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(s.s0, s.s1, (uint64_t)h->first, h->n, (const uint64_t *)h->staging, jt.levels,
+                                                             h->s0[h->cur], h->s1[h->cur]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_phases(dsim_handle h, double *phases) {
+  if (!h || !phases) return fail(DSIM_ERR_INVALID, "dsim_get_phases: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(phases, h->phase, (size_t)h->M * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_iter_exc(dsim_handle h, uint8_t *exc) {
+  if (!h || !exc) return fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(exc, h->exc, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_exceeded) {
+  if (!h || !out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  dim3 grid(h->sig_blocks, h->M);
+  signal_partial_kernel<<<grid, 256, 0, h->stream>>>(h->phase, h->exc, h->n, h->partial);
+  HIP_TRY(hipGetLastError());
+  signal_final_kernel<<<h->M + 1, 64, 0, h->stream>>>(h->partial, h->sig_blocks, h->exc, h->n, h->M, h->sig_out);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> out((size_t)2 * h->M + 1);
+  HIP_TRY(hipMemcpyAsync(out.data(), h->sig_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int m = 0; m < h->M; m++) {
+    out_cos[m] = out[m];
+    if (out_sin) out_sin[m] = out[h->M + m];
+  }
+  if (n_exceeded) *n_exceeded = (int64_t)out[2 * h->M];
+  return DSIM_OK;
+}
+
+/* ------------------------------------------------------------------- mesh --- */
+
+static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
+                       int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                       const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs) {
+  if (!vertices || !faces || !xs || !ys || !zs || !n_sv || !subvoxel_indices || (!triangle_indices && n_refs))
+    return fail(DSIM_ERR_INVALID, "mesh: null argument");
+  if (n_faces <= 0 || n_vertices <= 0 || n_faces > INT32_MAX || n_refs > INT32_MAX || n_refs < 0)
+    return fail(DSIM_ERR_INVALID, "mesh: bad sizes");
+  for (int k = 0; k < 3; k++)
+    if (n_sv[k] < 1 || n_sv[k] > 4096) return fail(DSIM_ERR_INVALID, "mesh: n_sv[%d] = %lld out of range", k, (long long)n_sv[k]);
+  const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
+  if (n_sub > INT32_MAX) return fail(DSIM_ERR_INVALID, "mesh: too many subvoxels");
+  free_mesh(dm);
+  /* pre-gathered triangle records {A, B - A, C - A} (simulations.py:259-262 does these subtractions per candidate) */
+  std::vector<double> rec((size_t)n_faces * 9);
+  for (int64_t f = 0; f < n_faces; f++) {
+    int64_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
+    if (ia < 0 || ib < 0 || ic < 0 || ia >= n_vertices || ib >= n_vertices || ic >= n_vertices)
+      return fail(DSIM_ERR_INVALID, "mesh: face %lld references a vertex out of range", (long long)f);
+    for (int k = 0; k < 3; k++) {
+      double a = vertices[ia * 3 + k];
+      rec[f * 9 + k] = a;
+      rec[f * 9 + 3 + k] = vertices[ib * 3 + k] - a;
+      rec[f * 9 + 6 + k] = vertices[ic * 3 + k] - a;
+    }
+  }
+  std::vector<int2> ranges((size_t)n_sub);
+  for (int64_t s = 0; s < n_sub; s++) {
+    int64_t a = subvoxel_indices[s * 2], b = subvoxel_indices[s * 2 + 1];
+    if (a < 0 || b < a || b > n_refs) return fail(DSIM_ERR_INVALID, "mesh: subvoxel %lld has a bad range", (long long)s);
+    ranges[s] = make_int2((int)a, (int)b);
+  }
+  std::vector<int32_t> refs((size_t)std::max<int64_t>(n_refs, 1));
+  for (int64_t i = 0; i < n_refs; i++) {
+    if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
+    refs[i] = (int32_t)triangle_indices[i];
+  }
+  std::vector<double> bounds;
+  bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
+  bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
+  bounds.insert(bounds.end(), zs, zs + n_sv[2] + 1);
+  HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
+  HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
+  HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.tri_idx, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.bounds, bounds.data(), bounds.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  dm.nx = (int)n_sv[0];
+  dm.ny = (int)n_sv[1];
+  dm.nz = (int)n_sv[2];
+  const double *b3[3] = {xs, ys, zs};
+  for (int k = 0; k < 3; k++) {
+    double L = b3[k][n_sv[k]] - b3[k][0];
+    dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
+  }
+  dm.set = true;
+  return DSIM_OK;
+}
+
+static MeshDev mesh_dev(const DevMesh &dm) {
+  MeshDev m;
+  m.tri = dm.tri;
+  m.sv_range = dm.sv_range;
+  m.tri_idx = dm.tri_idx;
+  m.bounds = dm.bounds;
+  m.nx = dm.nx;
+  m.ny = dm.ny;
+  m.nz = dm.nz;
+  m.inv_hx = dm.inv_h[0];
+  m.inv_hy = dm.inv_h[1];
+  m.inv_hz = dm.inv_h[2];
+  return m;
+}
+
+extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                             const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                             const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return upload_mesh(h->mesh, h->stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs);
+}
+
+/* ------------------------------------------------------------------ launch --- */
+
+template <int GEOM, int MB>
+static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s) {
+  walk_kernel<GEOM, MB><<<grid, block, lds, s>>>(p);
+  return hipGetLastError();
+}
+
+template <int GEOM>
+static hipError_t launch_mb(int mb, const WalkParams &p, int grid, int block, size_t lds, hipStream_t s) {
+  switch (mb) {
+    case 1: return launch_one<GEOM, 1>(p, grid, block, lds, s);
+    case 2: return launch_one<GEOM, 2>(p, grid, block, lds, s);
+    case 4: return launch_one<GEOM, 4>(p, grid, block, lds, s);
+    case 8: return launch_one<GEOM, 8>(p, grid, block, lds, s);
+    case 16: return launch_one<GEOM, 16>(p, grid, block, lds, s);
+    default: return launch_one<GEOM, 32>(p, grid, block, lds, s);
+  }
+}
+
+static int pick_mb(int M, int forced) {
+  int cap = forced > 0 ? forced : 32;
+  int mb = 1;
+  while (mb < M && mb < cap && mb < 32) mb <<= 1;
+  return mb;
+}
+
+static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_t t_end) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (t_begin < 0 || t_end > h->T || t_begin > t_end) return fail(DSIM_ERR_INVALID, "time range [%d, %d) outside [0, %d)", t_begin, t_end, h->T);
+  HIP_TRY(hipSetDevice(h->device));
+  h->last_ms = 0;
+  h->last_launches = 0;
+  if (t_begin == t_end) return DSIM_OK;
+  const int mb = pick_mb(h->M, h->meas_per_pass);
+  const int passes = (h->M + mb - 1) / mb;
+  const int src = h->cur, dst = passes > 1 ? 1 - h->cur : h->cur;
+  p.n = h->n;
+  p.x_in = h->x[src];
+  p.y_in = h->y[src];
+  p.z_in = h->z[src];
+  p.s0_in = h->s0[src];
+  p.s1_in = h->s1[src];
+  p.x_out = h->x[dst];
+  p.y_out = h->y[dst];
+  p.z_out = h->z[dst];
+  p.s0_out = h->s0[dst];
+  p.s1_out = h->s1[dst];
+  p.phase = h->phase;
+  p.exc = h->exc;
+  p.g4 = h->g4;
+  p.M = h->M;
+  p.t_begin = t_begin;
+  p.t_end = t_end;
+  p.step_l = h->step_l;
+  p.gdt = DSIM_GAMMA * h->dt;
+  /* LDS budget: 1 KB log table + subvoxel boundaries + <= 16 KB of gradient tile */
+  int tile = h->tile_steps > 0 ? h->tile_steps : std::max(1, 16384 / (mb * 32));
+  tile = std::min(tile, t_end - t_begin);
+  tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
+  p.tile_steps = tile;
+  int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
+  size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);
+  if (lds > 64 * 1024) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
+  const int block = h->block_size;
+  const int grid = grid_for(h->n, block);
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int pass = 0; pass < passes; pass++) {
+    p.m0 = pass * mb;
+    p.mc = std::min(mb, h->M - p.m0);
+    p.write_state = pass == passes - 1;
+    hipError_t e;
+    switch (geom) {
+      case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream); break;
+      case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream); break;
+      case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream); break;
+      case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream); break;
+      default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream); break;
+    }
+    if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    h->last_launches++;
+  }
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->last_ms = ms;
+  h->cur = dst;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (ms) *ms = h->last_ms;
+  if (n_launches) *n_launches = h->last_launches;
+  return DSIM_OK;
+}
+
+static int check_iter(int64_t max_iter, double eps) {
+  if (max_iter < 1) return fail(DSIM_ERR_INVALID, "max_iter must be >= 1");
+  if (!(eps == eps)) return fail(DSIM_ERR_INVALID, "epsilon is NaN");
+  return DSIM_OK;
+}
+
+extern "C" int dsim_run_free(dsim_handle h, int32_t t_begin, int32_t t_end) {
+  WalkParams p = {};
+  p.max_iter = 1;
+  return run_impl(h, GEOM_FREE, p, t_begin, t_end);
+}
+
+extern "C" int dsim_run_sphere(dsim_handle h, double radius, int64_t max_iter, double epsilon, int32_t t_begin, int32_t t_end) {
+  if (!(radius > 0)) return fail(DSIM_ERR_INVALID, "radius must be > 0");
+  int rc = check_iter(max_iter, epsilon);
+  if (rc) return rc;
+  WalkParams p = {};
+  p.radius = radius;
+  p.max_iter = max_iter;
+  p.eps = epsilon;
+  return run_impl(h, GEOM_SPHERE, p, t_begin, t_end);
+}
+
+extern "C" int dsim_run_cylinder(dsim_handle h, double radius, const double R[9], const double R_inv[9], int64_t max_iter,
+                                 double epsilon, int32_t t_begin, int32_t t_end) {
+  if (!(radius > 0) || !R || !R_inv) return fail(DSIM_ERR_INVALID, "bad cylinder arguments");
+  int rc = check_iter(max_iter, epsilon);
+  if (rc) return rc;
+  WalkParams p = {};
+  p.radius = radius;
+  memcpy(p.R, R, sizeof(p.R));
+  memcpy(p.Rinv, R_inv, sizeof(p.Rinv));
+  p.max_iter = max_iter;
+  p.eps = epsilon;
+  return run_impl(h, GEOM_CYLINDER, p, t_begin, t_end);
+}
+
+extern "C" int dsim_run_ellipsoid(dsim_handle h, const double semiaxes[3], const double R[9], const double R_inv[9],
+                                  int64_t max_iter, double epsilon, int32_t t_begin, int32_t t_end) {
+  if (!semiaxes || !R || !R_inv) return fail(DSIM_ERR_INVALID, "bad ellipsoid arguments");
+  int rc = check_iter(max_iter, epsilon);
+  if (rc) return rc;
+  WalkParams p = {};
+  memcpy(p.ax, semiaxes, sizeof(p.ax));
+  memcpy(p.R, R, sizeof(p.R));
+  memcpy(p.Rinv, R_inv, sizeof(p.Rinv));
+  p.max_iter = max_iter;
+  p.eps = epsilon;
+  return run_impl(h, GEOM_ELLIPSOID, p, t_begin, t_end);
+}
+
+extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, double perm_prob, int32_t t_begin, int32_t t_end) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (!h->mesh.set) return fail(DSIM_ERR_STATE, "dsim_run_mesh called before dsim_set_mesh");
+  int rc = check_iter(max_iter, epsilon);
+  if (rc) return rc;
+  WalkParams p = {};
+  p.max_iter = max_iter;
+  p.eps = epsilon;
+  p.perm_prob = perm_prob;
+  p.mesh = mesh_dev(h->mesh);
+  return run_impl(h, GEOM_MESH, p, t_begin, t_end);
+}
+
+/* -------------------------------------------------------------- fill_mesh --- */
+
+__global__ void fill_inf_kernel(double *px, double *py, double *pz, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    px[i] = DS_INF;
+    py[i] = DS_INF;
+    pz[i] = DS_INF;
+  }
+}
+
+extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const double *vertices, int64_t n_vertices,
+                              const int64_t *faces, int64_t n_faces, const double voxel_size[3], const double *xs,
+                              const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                              const int64_t *triangle_indices, int64_t n_refs, double *out_points) {
+  if (n_points <= 0 || !out_points || !voxel_size) return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: bad arguments");
+  int ndev = dsim_device_count();
+  if (ndev <= 0) return fail(DSIM_ERR_NO_DEVICE, "no HIP device visible (need an AMD GPU with ROCm)");
+  if (device < 0 || device >= ndev) return fail(DSIM_ERR_INVALID, "device out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t stream;
+  HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  DevMesh dm;
+  double *px = nullptr, *py = nullptr, *pz = nullptr;
+  uint64_t *s0 = nullptr, *s1 = nullptr, *cols = nullptr;
+  int rc = upload_mesh(dm, stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs);
+  auto cleanup = [&]() {
+    free_mesh(dm);
+    if (px) (void)hipFree(px);
+    if (py) (void)hipFree(py);
+    if (pz) (void)hipFree(pz);
+    if (s0) (void)hipFree(s0);
+    if (s1) (void)hipFree(s1);
+    if (cols) (void)hipFree(cols);
+    (void)hipStreamDestroy(stream);
+  };
+#define FILL_TRY(expr)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      cleanup();                                                                           \
+      return fail(DSIM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));             \
+    }                                                                                      \
+  } while (0)
+  if (rc) {
+    std::string keep = g_err;
+    cleanup();
+    g_err = keep;
+    return rc;
+  }
+  FILL_TRY(hipMalloc(&px, n_points * sizeof(double)));
+  FILL_TRY(hipMalloc(&py, n_points * sizeof(double)));
+  FILL_TRY(hipMalloc(&pz, n_points * sizeof(double)));
+  FILL_TRY(hipMalloc(&s0, n_points * sizeof(uint64_t)));
+  FILL_TRY(hipMalloc(&s1, n_points * sizeof(uint64_t)));
+  /* own RNG states with the same seed (simulations.py:524): thread i <- state i */
+  const JumpTables &jt = jump_tables();
+  FILL_TRY(hipMalloc(&cols, jt.cols.size() * sizeof(HostRng)));
+  FILL_TRY(hipMemcpyAsync(cols, jt.cols.data(), jt.cols.size() * sizeof(HostRng), hipMemcpyHostToDevice, stream));
+  HostRng sd = h_seed_state(seed);
+  const int grid = grid_for(n_points, 256);
+  rng_init_kernel<<<grid, 256, 0, stream>>>(sd.s0, sd.s1, 0, n_points, cols, jt.levels, s0, s1);
+  FILL_TRY(hipGetLastError());
+  FillParams fp;
+  fp.n_points = n_points;
+  fp.px = px;
+  fp.py = py;
+  fp.pz = pz;
+  fp.s0 = s0;
+  fp.s1 = s1;
+  fp.intra = intra ? 1 : 0;
+  for (int k = 0; k < 3; k++) fp.voxel[k] = voxel_size[k];
+  fp.mesh = mesh_dev(dm);
+  const size_t lds = (size_t)(dm.nx + dm.ny + dm.nz + 3) * sizeof(double);
+  std::vector<double> hx((size_t)n_points), hy((size_t)n_points), hz((size_t)n_points);
+  int64_t have = 0;
+  int launches = 0;
+  while (have < n_points) {
+    if (++launches > 100000) {
+      cleanup();
+      return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 100000 launches (is the surface closed?)");
+    }
+    fill_inf_kernel<<<grid, 256, 0, stream>>>(px, py, pz, n_points);
+    FILL_TRY(hipGetLastError());
+    fill_mesh_kernel<<<grid, 256, lds, stream>>>(fp);
+    FILL_TRY(hipGetLastError());
+    FILL_TRY(hipMemcpyAsync(hx.data(), px, n_points * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FILL_TRY(hipMemcpyAsync(hy.data(), py, n_points * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FILL_TRY(hipMemcpyAsync(hz.data(), pz, n_points * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FILL_TRY(hipStreamSynchronize(stream));
+    /* keep finite rows in thread order (simulations.py:573-576) */
+    for (int64_t i = 0; i < n_points && have < n_points; i++)
+      if (!std::isinf(hx[i])) {
+        out_points[have * 3] = hx[i];
+        out_points[have * 3 + 1] = hy[i];
+        out_points[have * 3 + 2] = hz[i];
+        have++;
+      }
+  }
+  cleanup();
+  return DSIM_OK;
+#undef FILL_TRY
+}
+
+/* -------------------------------------------- mesh subdivision (host only) --- */
+/* substrates.py:272-536, restated operation by operation in IEEE double WITHOUT
+ * fused multiply-adds (the reference runs this part as plain numpy / numba CPU
+ * code), so that membership matches the reference's .npy fixtures exactly. */
+
+static inline double sd_dot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void sd_cross(const double *a, const double *b, double *c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* substrates.py:291-368 (Akenine-Moller SAT); tri (3,3), box (2,3) */
+static bool triangle_box_overlap(const double tri[9], const double box[6]) {
+  double c[3], hh[3], v[9];
+  for (int i = 0; i < 3; i++) {
+    c[i] = (box[i] + box[3 + i]) / 2.0; /* np.mean of two values */
+    hh[i] = std::fabs(box[3 + i] - box[i]) / 2;
+  }
+  for (int k = 0; k < 3; k++)
+    for (int i = 0; i < 3; i++) v[k * 3 + i] = tri[k * 3 + i] - c[i];
+  /* triangle AABB against the box: the reference rejects only if ALL three axes are outside (:323) */
+  bool all_above = true, all_below = true;
+  for (int i = 0; i < 3; i++) {
+    double mn = std::min(v[i], std::min(v[3 + i], v[6 + i]));
+    double mx = std::max(v[i], std::max(v[3 + i], v[6 + i]));
+    if (!(mn > hh[i])) all_above = false;
+    if (!(mx < -hh[i])) all_below = false;
+  }
+  if (all_above || all_below) return false;
+  double f[9];
+  for (int i = 0; i < 3; i++) {
+    f[i] = v[3 + i] - v[i];
+    f[3 + i] = v[6 + i] - v[3 + i];
+    f[6 + i] = v[i] - v[6 + i];
+  }
+  double normal[3];
+  sd_cross(f, f + 3, normal);
+  const double sg[8][3] = {{1, 1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}};
+  bool in_plane = false, all_behind = true, none_behind = true;
+  for (int k = 0; k < 8; k++) {
+    double d[3];
+    for (int i = 0; i < 3; i++) d[i] = v[i] - sg[k][i] * hh[i];
+    double dp = sd_dot(normal, d);
+    bool behind = false;
+    if (dp == 0)
+      in_plane = true;
+    else
+      behind = dp > 0;
+    if (behind)
+      none_behind = false;
+    else
+      all_behind = false;
+  }
+  if (!in_plane && (all_behind || none_behind)) return false;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double e[3] = {0, 0, 0};
+      e[i] = 1.0;
+      double a[3];
+      sd_cross(e, f + 3 * j, a);
+      double aa[3] = {std::fabs(a[0]), std::fabs(a[1]), std::fabs(a[2])};
+      double r = sd_dot(hh, aa);
+      double p0 = sd_dot(a, v), p1 = sd_dot(a, v + 3), p2 = sd_dot(a, v + 6);
+      double mn = std::min(p0, std::min(p1, p2)), mx = std::max(p0, std::max(p1, p2));
+      if (mn > r || mx < -r) return false;
+    }
+  return true;
+}
+
+/* substrates.py:371-419 */
+static void interval_sv_overlap(const double *xs, int64_t len, double x1, double x2, int64_t *ll_out, int64_t *ul_out) {
+  double xmin = std::min(x1, x2), xmax = std::max(x1, x2);
+  int64_t ll, ul;
+  if (xmin <= xs[0])
+    ll = 0;
+  else if (xmin >= xs[len - 1])
+    ll = len - 1;
+  else {
+    ll = 0;
+    for (int64_t i = 0; i < len; i++)
+      if (xs[i] > xmin) {
+        ll = i - 1;
+        break;
+      }
+  }
+  if (xmax >= xs[len - 1])
+    ul = len - 1;
+  else if (xmax <= xs[0])
+    ul = 0;
+  else {
+    ul = len - 1;
+    for (int64_t i = 0; i < len; i++)
+      if (!(xs[i] < xmax)) {
+        ul = i;
+        break;
+      }
+  }
+  if (ll != ul) {
+    *ll_out = ll;
+    *ul_out = ul;
+  } else if (ll != len - 1) {
+    *ll_out = ll;
+    *ul_out = ul + 1;
+  } else {
+    *ll_out = ll - 1;
+    *ul_out = ul;
+  }
+}
+
+extern "C" int dsim_triangle_box_overlap(const double triangle[9], const double box[6]) {
+  if (!triangle || !box) return fail(DSIM_ERR_INVALID, "dsim_triangle_box_overlap: null argument");
+  return triangle_box_overlap(triangle, box) ? 1 : 0;
+}
+
+extern "C" int dsim_interval_sv_overlap(const double *xs, int64_t n_xs, double x1, double x2, int64_t *ll, int64_t *ul) {
+  if (!xs || n_xs < 2 || !ll || !ul) return fail(DSIM_ERR_INVALID, "dsim_interval_sv_overlap: bad argument");
+  interval_sv_overlap(xs, n_xs, x1, x2, ll, ul);
+  return DSIM_OK;
+}
+
+extern "C" int dsim_mesh_subdivide(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                                   const double *xs_in, const double *ys_in, const double *zs_in, const int64_t n_sv[3],
+                                   int64_t *subvoxel_indices, int64_t *triangle_indices, int64_t *n_refs) {
+  if (!vertices || !faces || !xs_in || !ys_in || !zs_in || !n_sv || !n_refs)
+    return fail(DSIM_ERR_INVALID, "dsim_mesh_subdivide: null argument");
+  for (int k = 0; k < 3; k++)
+    if (n_sv[k] < 1) return fail(DSIM_ERR_INVALID, "dsim_mesh_subdivide: n_sv must be >= 1");
+  const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
+  std::vector<double> xs(xs_in, xs_in + n_sv[0] + 1), ys(ys_in, ys_in + n_sv[1] + 1), zs(zs_in, zs_in + n_sv[2] + 1);
+  /* two passes over (triangle, subvoxel) pairs in the reference's order: count, then fill (CSR) */
+  std::vector<int64_t> count((size_t)n_sub, 0);
+  std::vector<std::pair<int64_t, int64_t>> pairs; /* (subvoxel, triangle), generated in triangle order */
+  for (int64_t f = 0; f < n_faces; f++) {
+    double tri[9];
+    for (int a = 0; a < 3; a++) {
+      int64_t vi = faces[f * 3 + a];
+      if (vi < 0 || vi >= n_vertices) return fail(DSIM_ERR_INVALID, "dsim_mesh_subdivide: face %lld out of range", (long long)f);
+      for (int b = 0; b < 3; b++) tri[a * 3 + b] = vertices[vi * 3 + b];
+    }
+    int64_t lo[3], hi[3];
+    const std::vector<double> *ax[3] = {&xs, &ys, &zs};
+    for (int k = 0; k < 3; k++) {
+      double mn = std::min(tri[k], std::min(tri[3 + k], tri[6 + k]));
+      double mx = std::max(tri[k], std::max(tri[3 + k], tri[6 + k]));
+      interval_sv_overlap(ax[k]->data(), (int64_t)ax[k]->size(), mn, mx, &lo[k], &hi[k]);
+    }
+    for (int64_t x = lo[0]; x < hi[0]; x++)
+      for (int64_t y = lo[1]; y < hi[1]; y++)
+        for (int64_t z = lo[2]; z < hi[2]; z++) {
+          double box[6] = {xs[x], ys[y], zs[z], xs[x + 1], ys[y + 1], zs[z + 1]};
+          if (triangle_box_overlap(tri, box)) {
+            int64_t sv = x * n_sv[1] * n_sv[2] + y * n_sv[2] + z;
+            count[sv]++;
+            pairs.emplace_back(sv, f);
+          }
+        }
+  }
+  *n_refs = (int64_t)pairs.size();
+  if (subvoxel_indices) {
+    int64_t c = 0;
+    for (int64_t s = 0; s < n_sub; s++) {
+      subvoxel_indices[s * 2] = c;
+      c += count[s];
+      subvoxel_indices[s * 2 + 1] = c;
+    }
+  }
+  if (triangle_indices) {
+    if (!subvoxel_indices) return fail(DSIM_ERR_INVALID, "dsim_mesh_subdivide: triangle_indices needs subvoxel_indices");
+    std::vector<int64_t> cursor((size_t)n_sub);
+    for (int64_t s = 0; s < n_sub; s++) cursor[s] = subvoxel_indices[s * 2];
+    for (auto &pr : pairs) triangle_indices[cursor[pr.first]++] = pr.second; /* triangle order kept within a subvoxel */
+  }
+  return DSIM_OK;
+}

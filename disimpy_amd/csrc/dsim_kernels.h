@@ -1,0 +1,483 @@
+/* dsim_kernels.h - the fused random-walk kernels (gfx950, wave64).
+ *
+ * One launch advances every walker over a whole range of time steps
+ * [t_begin, t_end) (the reference launches one kernel per step and round-trips
+ * positions, RNG state and the (M,N) phase matrix through HBM each time,
+ * simulations.py:1198-1216).  Per walker, position + xoroshiro128+ state + MB
+ * phase accumulators stay in registers for the whole range; HBM is touched
+ * once at the start and once at the end (SoA, one 8-byte lane per wavefront
+ * lane => fully coalesced).  LDS holds (a) the 1 KB log table of ds_logf,
+ * (b) the subvoxel boundaries of the mesh index, (c) the current tile of the
+ * gradient waveform, laid out [step][measurement][x y z pad] so that every lane
+ * of a wavefront reads the same address (LDS broadcast, no bank conflict).
+ */
+#ifndef DSIM_KERNELS_H
+#define DSIM_KERNELS_H
+
+#include "dsim_device.h"
+
+enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };
+
+struct MeshDev {
+  const double *tri;       /* [n_faces][9]  {A, E1, E2}                  */
+  const int2 *sv_range;    /* [prod n_sv]   [start, end) into tri_idx    */
+  const int32_t *tri_idx;  /* [n_refs]                                   */
+  const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
+  int nx, ny, nz;
+  double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
+};
+
+struct WalkParams {
+  int64_t n;
+  const double *x_in, *y_in, *z_in;
+  const uint64_t *s0_in, *s1_in;
+  double *x_out, *y_out, *z_out;
+  uint64_t *s0_out, *s1_out;
+  double *phase;      /* (M, n) */
+  uint8_t *exc;       /* (n,)   */
+  const double *g4;   /* [T][M][4] = gx, gy, gz, 0 */
+  int M, m0, mc;      /* this pass handles measurements [m0, m0+mc), mc <= MB */
+  int t_begin, t_end, tile_steps;
+  int write_state;    /* last pass writes positions / RNG state / exc */
+  double step_l, gdt; /* gdt = GAMMA * dt (gradients.py:13) */
+  double radius;
+  double ax[3];
+  double R[9], Rinv[9];
+  int64_t max_iter;
+  double eps, perm_prob;
+  MeshDev mesh;
+};
+
+/* ---- one walker, one time step, by substrate -------------------------------- */
+
+/* simulations.py:705-745 */
+DSD void step_sphere(V3 &r0, V3 &step, double step_l, const WalkParams &p, bool &exc) {
+  int64_t iter_idx = 0;
+  bool check = true;
+  while (check && step_l > 0 && iter_idx < p.max_iter) {
+    iter_idx++;
+    double d = line_sphere_intersection(r0, step, p.radius);
+    if (d > 0 && d < step_l) {
+      V3 n = {-__builtin_fma(d, step.x, r0.x), -__builtin_fma(d, step.y, r0.y), -__builtin_fma(d, step.z, r0.z)};
+      normalize3(n);
+      reflection(r0, step, d, n, p.eps);
+      step_l -= d + p.eps;
+    } else {
+      check = false;
+    }
+  }
+  if (iter_idx >= p.max_iter) exc = true;
+  r0.x = __builtin_fma(step.x, step_l, r0.x);
+  r0.y = __builtin_fma(step.y, step_l, r0.y);
+  r0.z = __builtin_fma(step.z, step_l, r0.z);
+}
+
+/* simulations.py:759-805 */
+DSD void step_cylinder(V3 &r0, V3 &step, double step_l, const WalkParams &p, bool &exc) {
+  r0 = mat_mul(p.R, r0);
+  int64_t iter_idx = 0;
+  bool check = true;
+  while (check && step_l > 0 && iter_idx < p.max_iter) {
+    iter_idx++;
+    double d = line_circle_intersection(r0.y, r0.z, step.y, step.z, p.radius);
+    if (d > 0 && d < step_l) {
+      V3 n = {0.0, -__builtin_fma(d, step.y, r0.y), -__builtin_fma(d, step.z, r0.z)};
+      normalize3(n);
+      reflection(r0, step, d, n, p.eps);
+      step_l -= d + p.eps;
+    } else {
+      check = false;
+    }
+  }
+  if (iter_idx >= p.max_iter) exc = true;
+  step = mat_mul(p.Rinv, step);
+  r0 = mat_mul(p.Rinv, r0);
+  r0.x = __builtin_fma(step.x, step_l, r0.x);
+  r0.y = __builtin_fma(step.y, step_l, r0.y);
+  r0.z = __builtin_fma(step.z, step_l, r0.z);
+}
+
+/* simulations.py:819-864 */
+DSD void step_ellipsoid(V3 &r0, V3 &step, double step_l, const WalkParams &p, bool &exc) {
+  r0 = mat_mul(p.R, r0);
+  int64_t iter_idx = 0;
+  bool check = true;
+  while (check && step_l > 0 && iter_idx < p.max_iter) {
+    iter_idx++;
+    double d = line_ellipsoid_intersection(r0, step, p.ax[0], p.ax[1], p.ax[2]);
+    if (d > 0 && d < step_l) {
+      V3 n = {-__builtin_fma(d, step.x, r0.x) / (p.ax[0] * p.ax[0]), -__builtin_fma(d, step.y, r0.y) / (p.ax[1] * p.ax[1]),
+              -__builtin_fma(d, step.z, r0.z) / (p.ax[2] * p.ax[2])};
+      normalize3(n);
+      reflection(r0, step, d, n, p.eps);
+      step_l -= d + p.eps;
+    } else {
+      check = false;
+    }
+  }
+  if (iter_idx >= p.max_iter) exc = true;
+  step = mat_mul(p.Rinv, step);
+  r0 = mat_mul(p.Rinv, r0);
+  r0.x = __builtin_fma(step.x, step_l, r0.x);
+  r0.y = __builtin_fma(step.y, step_l, r0.y);
+  r0.z = __builtin_fma(step.z, step_l, r0.z);
+}
+
+DSD V3 load_v3(const double *p) {
+  V3 v = {p[0], p[1], p[2]};
+  return v;
+}
+
+/* simulations.py:878-1002.  xs/ys/zs: LDS copies of the subvoxel boundaries. */
+DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const double *xs, const double *ys,
+                   const double *zs, Rng &rng, bool &exc) {
+  const MeshDev &ms = p.mesh;
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
+  int64_t iter_idx = 0;
+  bool check = true;
+  int closest = 0;
+  while (check && step_l > 0 && iter_idx < p.max_iter) {
+    iter_idx++;
+    double min_d = DS_INF;
+    double ex = __builtin_fma(step.x, step_l, r0.x);
+    double ey = __builtin_fma(step.y, step_l, r0.y);
+    double ez = __builtin_fma(step.z, step_l, r0.z);
+    int llx = ll_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, r0.x, ex);
+    int lly = ll_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, r0.y, ey);
+    int llz = ll_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, r0.z, ez);
+    int ulx = ul_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, r0.x, ex);
+    int uly = ul_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, r0.y, ey);
+    int ulz = ul_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, r0.z, ez);
+    for (int xi = llx; xi < ulx; xi++) {
+      int x = xi;
+      double shx = 0;
+      if (x < 0 || x > nx - 1) {
+        int sn = floor_div(x, nx);
+        x -= sn * nx;
+        shx = (double)sn * Lx;
+      }
+      for (int yi = lly; yi < uly; yi++) {
+        int y = yi;
+        double shy = 0;
+        if (y < 0 || y > ny - 1) {
+          int sn = floor_div(y, ny);
+          y -= sn * ny;
+          shy = (double)sn * Ly;
+        }
+        for (int zi = llz; zi < ulz; zi++) {
+          int z = zi;
+          double shz = 0;
+          if (z < 0 || z > nz - 1) {
+            int sn = floor_div(z, nz);
+            z -= sn * nz;
+            shz = (double)sn * Lz;
+          }
+          int sv = (x * ny + y) * nz + z;
+          V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
+          int2 range = ms.sv_range[sv];
+          for (int i = range.x; i < range.y; i++) {
+            int ti = ms.tri_idx[i];
+            const double *rec = ms.tri + (int64_t)ti * 9;
+            double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
+            if (d > 0 && d < min_d) {
+              closest = ti;
+              min_d = d;
+            }
+          }
+        }
+      }
+    }
+    if (min_d > step_l) {
+      check = false;
+    } else {
+      bool reflect = p.perm_prob < rng_uniform_f64(rng);
+      const double *rec = ms.tri + (int64_t)closest * 9;
+      V3 n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
+      normalize3(n);
+      if (reflect)
+        reflection(r0, step, min_d, n, p.eps);
+      else
+        crossing(r0, step, min_d, n, p.eps);
+      step_l -= min_d;
+    }
+  }
+  if (iter_idx >= p.max_iter) exc = true;
+  r0.x = __builtin_fma(step.x, step_l, r0.x);
+  r0.y = __builtin_fma(step.y, step_l, r0.y);
+  r0.z = __builtin_fma(step.z, step_l, r0.z);
+}
+
+/* ---- the fused kernel --------------------------------------------------------- */
+
+template <int GEOM, int MB>
+__global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
+  extern __shared__ double lds[];
+  double *log_tab = lds;                           /* 128 doubles                     */
+  double *bounds = lds + DS_LOG_TABLE_DOUBLES;     /* mesh only                       */
+  int n_bounds = 0;
+  if (GEOM == GEOM_MESH) n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
+  double *gt = bounds + ((n_bounds + 1) & ~1);     /* gradient tile, 16-byte aligned  */
+
+  for (int i = threadIdx.x; i < DS_LOG_TABLE_DOUBLES; i += blockDim.x) log_tab[i] = ds_log_table_dev[i];
+  if (GEOM == GEOM_MESH)
+    for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) bounds[i] = p.mesh.bounds[i];
+  const double *xs = bounds, *ys = bounds + p.mesh.nx + 1, *zs = bounds + p.mesh.nx + p.mesh.ny + 2;
+
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < p.n;
+  V3 r = {0, 0, 0};
+  Rng rng = {1, 1};
+  bool exc = false;
+  double ph[MB];
+#pragma unroll
+  for (int m = 0; m < MB; m++) ph[m] = 0;
+  if (live) {
+    r.x = p.x_in[i];
+    r.y = p.y_in[i];
+    r.z = p.z_in[i];
+    rng.s0 = p.s0_in[i];
+    rng.s1 = p.s1_in[i];
+    exc = p.exc[i] != 0;
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+      if (m < p.mc) ph[m] = p.phase[(int64_t)(p.m0 + m) * p.n + i];
+  }
+
+  for (int t0 = p.t_begin; t0 < p.t_end; t0 += p.tile_steps) {
+    const int kt = min(p.tile_steps, p.t_end - t0);
+    __syncthreads(); /* previous tile fully consumed (also orders the table fills above) */
+    {
+      /* tile rows are contiguous runs of mc*4 doubles inside g4[t][M][4] */
+      const int row = p.mc * 2; /* double2 per step */
+      const double2 *src = reinterpret_cast<const double2 *>(p.g4);
+      double2 *dst = reinterpret_cast<double2 *>(gt);
+      for (int e = threadIdx.x; e < kt * row; e += blockDim.x) {
+        int k = e / row, c = e - k * row;
+        dst[k * (MB * 2) + c] = src[((int64_t)(t0 + k) * p.M + p.m0) * 2 + c];
+      }
+    }
+    __syncthreads();
+    if (live) {
+      for (int k = 0; k < kt; k++) {
+        V3 step = random_step(rng, log_tab);
+        if (GEOM == GEOM_FREE) {
+          /* simulations.py:690-691 */
+          r.x = __builtin_fma(step.x, p.step_l, r.x);
+          r.y = __builtin_fma(step.y, p.step_l, r.y);
+          r.z = __builtin_fma(step.z, p.step_l, r.z);
+        } else if (GEOM == GEOM_SPHERE) {
+          step_sphere(r, step, p.step_l, p, exc);
+        } else if (GEOM == GEOM_CYLINDER) {
+          step_cylinder(r, step, p.step_l, p, exc);
+        } else if (GEOM == GEOM_ELLIPSOID) {
+          step_ellipsoid(r, step, p.step_l, p, exc);
+        } else {
+          step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
+        }
+        /* phases[m, i] += GAMMA*dt*(gx*x + gy*y + gz*z), e.g. simulations.py:692-701 */
+        const double *g = gt + k * (MB * 4);
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+          if (m < p.mc) {
+            double2 gxy = *reinterpret_cast<const double2 *>(g + m * 4);
+            double gz = g[m * 4 + 2];
+            double inner = __builtin_fma(gz, r.z, __builtin_fma(gxy.x, r.x, gxy.y * r.y));
+            ph[m] = __builtin_fma(p.gdt, inner, ph[m]);
+          }
+        }
+      }
+    }
+  }
+
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+      if (m < p.mc) p.phase[(int64_t)(p.m0 + m) * p.n + i] = ph[m];
+    if (p.write_state) {
+      p.x_out[i] = r.x;
+      p.y_out[i] = r.y;
+      p.z_out[i] = r.z;
+      p.s0_out[i] = rng.s0;
+      p.s1_out[i] = rng.s1;
+      p.exc[i] = exc ? 1 : 0;
+    }
+  }
+}
+
+/* ---- signal: sum over walkers of cos/sin(phase), wavefront shuffles ----------- */
+
+DSD double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+/* grid = (blocks, M); partial[(m*gridDim.x + b)*2 + {0,1}] = block sums of cos, sin.
+ * Replaces phases D2H + np.nansum(np.exp(1j*phases)) (simulations.py:1413-1421):
+ * walkers with iter_exc set or a NaN phase contribute nothing. */
+__global__ __launch_bounds__(256) void signal_partial_kernel(const double *phase, const uint8_t *exc, int64_t n,
+                                                             double *partial) {
+  __shared__ double sc[4], ss[4];
+  const int m = blockIdx.y;
+  double c = 0, s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double ph = phase[(int64_t)m * n + i];
+    if (exc[i] == 0 && ph == ph) {
+      double sv, cv;
+      sincos(ph, &sv, &cv);
+      if (sv == sv && cv == cv) {
+        c += cv;
+        s += sv;
+      }
+    }
+  }
+  c = wave_sum(c);
+  s = wave_sum(s);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sc[wave] = c;
+    ss[wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tc = 0, ts = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+      tc += sc[w];
+      ts += ss[w];
+    }
+    partial[((int64_t)m * gridDim.x + blockIdx.x) * 2] = tc;
+    partial[((int64_t)m * gridDim.x + blockIdx.x) * 2 + 1] = ts;
+  }
+}
+
+/* one wavefront per measurement folds the block partials in a fixed order
+ * (deterministic, no float atomics); block M counts the exceeded walkers. */
+__global__ __launch_bounds__(64) void signal_final_kernel(const double *partial, int n_blocks, const uint8_t *exc,
+                                                          int64_t n, int M, double *out /* [2M + 1] */) {
+  const int m = blockIdx.x;
+  if (m < M) {
+    double c = 0, s = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 64) {
+      c += partial[((int64_t)m * n_blocks + b) * 2];
+      s += partial[((int64_t)m * n_blocks + b) * 2 + 1];
+    }
+    c = wave_sum(c);
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+      out[m] = c;
+      out[M + m] = s;
+    }
+  } else {
+    double cnt = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 64) cnt += exc[i] ? 1.0 : 0.0;
+    cnt = wave_sum(cnt);
+    if (threadIdx.x == 0) out[2 * M] = cnt;
+  }
+}
+
+/* ---- layout conversion ---------------------------------------------------------- */
+
+__global__ void aos_to_soa_kernel(const double *aos, int64_t n, double *x, double *y, double *z) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    x[i] = aos[i * 3];
+    y[i] = aos[i * 3 + 1];
+    z[i] = aos[i * 3 + 2];
+  }
+}
+
+__global__ void soa_to_aos_kernel(const double *x, const double *y, const double *z, int64_t n, double *aos) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    aos[i * 3] = x[i];
+    aos[i * 3 + 1] = y[i];
+    aos[i * 3 + 2] = z[i];
+  }
+}
+
+__global__ void states_to_soa_kernel(const uint64_t *st, int64_t n, uint64_t *s0, uint64_t *s1) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    s0[i] = st[i * 2];
+    s1[i] = st[i * 2 + 1];
+  }
+}
+
+__global__ void soa_to_states_kernel(const uint64_t *s0, const uint64_t *s1, int64_t n, uint64_t *st) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    st[i * 2] = s0[i];
+    st[i * 2 + 1] = s1[i];
+  }
+}
+
+/* ---- _cuda_fill_mesh (simulations.py:421-502) ------------------------------------ */
+
+struct FillParams {
+  int64_t n_points;
+  double *px, *py, *pz; /* +inf where no point has been accepted yet */
+  uint64_t *s0, *s1;
+  int intra;
+  double voxel[3];
+  MeshDev mesh; /* tri_idx / sv_range may be the "stripped" index of non-periodic substrates */
+};
+
+#define FILL_MAX_HITS 1000
+
+__global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
+  extern __shared__ double lds[];
+  const int n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
+  for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) lds[i] = p.mesh.bounds[i];
+  __syncthreads();
+  const double *xs = lds, *ys = lds + p.mesh.nx + 1, *zs = lds + p.mesh.nx + p.mesh.ny + 2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= p.n_points || p.px[tid] != DS_INF) return;
+  Rng rng = {p.s0[tid], p.s1[tid]};
+  V3 pt;
+  pt.x = rng_uniform_f64(rng) * p.voxel[0];
+  pt.y = rng_uniform_f64(rng) * p.voxel[1];
+  pt.z = rng_uniform_f64(rng) * p.voxel[2];
+  p.s0[tid] = rng.s0;
+  p.s1[tid] = rng.s1;
+  const V3 ray = {1.0, 0.0, 0.0};
+  const MeshDev &ms = p.mesh;
+  /* non-periodic lookups (:455-460): ll on min(p, p+ray) = p, ul on max = p+ray */
+  int llx = ll_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x);
+  int lly = ll_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
+  int llz = ll_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+  int ulx = ul_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x + ray.x);
+  int uly = ul_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
+  int ulz = ul_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+  int n_hits = 0;
+  int32_t hits[FILL_MAX_HITS]; /* private (scratch) memory, like the reference's cuda.local.array(1000) */
+  for (int x = llx; x < ulx; x++)
+    for (int y = lly; y < uly; y++)
+      for (int z = llz; z < ulz; z++) {
+        int sv = (x * ms.ny + y) * ms.nz + z;
+        int2 range = ms.sv_range[sv];
+        for (int i = range.x; i < range.y; i++) {
+          if (n_hits >= FILL_MAX_HITS) return; /* :478-479: sample abandoned */
+          int ti = ms.tri_idx[i];
+          const double *rec = ms.tri + (int64_t)ti * 9;
+          double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
+          if (d > 0) {
+            bool already = false;
+            for (int j = 0; j < n_hits; j++)
+              if (hits[j] == ti) {
+                already = true;
+                break;
+              }
+            if (!already) hits[n_hits++] = ti;
+          }
+        }
+      }
+  bool inside = (n_hits & 1) == 1;
+  if (p.intra ? inside : !inside) {
+    p.px[tid] = pt.x;
+    p.py[tid] = pt.y;
+    p.pz[tid] = pt.z;
+  }
+}
+
+#endif /* DSIM_KERNELS_H */

@@ -1,0 +1,374 @@
+"""Diffusion-weighted MR simulation driver (mirror of disimpy/simulations.py).
+
+``simulation()`` keeps the reference's signature, validation, messages,
+warnings and return shapes (disimpy/simulations.py:1051-1429) but runs the
+whole time loop in fused HIP kernels on an MI355X through the C ABI of
+``include/dsim.h``: one launch per range of time steps instead of one launch +
+synchronisation per step, and the signal is reduced on the device instead of
+copying the (M, N) phase matrix to the host.  There is no CPU fallback.
+"""
+import math
+import sys
+import warnings
+
+import numpy as np
+
+from . import _lib, substrates, utils
+from .gradients import GAMMA  # noqa: F401  (re-exported like the reference)
+
+_NO_GPU_MESSAGE = (
+    "disimpy_amd was unable to detect an AMD GPU. To run the simulation, check that ROCm is installed, "
+    "that /dev/kfd is accessible and that disimpy_amd/csrc/libdsim_hip.so has been built for gfx950."
+)
+
+
+# ----------------------------------------------------------------------------
+# initial positions (host; disimpy/simulations.py:346-418)
+# ----------------------------------------------------------------------------
+
+
+def _rejection_sample(rng, n, dim, scale, inside):
+    """First ``n`` accepted points of the stream ``p = (u - 0.5) * 2 * scale`` with
+    ``u = rng.random_sample(dim)`` per attempt (attempt k consumes draws k*dim ..)."""
+    out = np.zeros((n, dim))
+    have = 0
+    while have < n:
+        batch = max(1024, int(2.2 * (n - have)))
+        p = (rng.random_sample((batch, dim)) - 0.5) * 2 * scale
+        p = p[inside(p)][: n - have]
+        out[have : have + len(p)] = p
+        have += len(p)
+    return out
+
+
+def _host_rng(seed):
+    """The reference seeds numba's CPU Mersenne Twister with ``np.random.seed(seed)``
+    inside a jitted function (disimpy/simulations.py:346-350); numba documents
+    it as the same MT19937 + 53-bit doubles as NumPy's legacy ``RandomState``."""
+    return np.random.RandomState(seed)
+
+
+def _fill_circle(n, radius, rng=None):
+    """n points uniformly inside a circle (disimpy/simulations.py:353-366)."""
+    rng = rng or _host_rng(None)
+    return _rejection_sample(rng, n, 2, radius, lambda p: np.linalg.norm(p, axis=1) < radius)
+
+
+def _fill_sphere(n, radius, rng=None):
+    """n points uniformly inside a sphere (disimpy/simulations.py:369-382)."""
+    rng = rng or _host_rng(None)
+    return _rejection_sample(rng, n, 3, radius, lambda p: np.linalg.norm(p, axis=1) < radius)
+
+
+def _fill_ellipsoid(n, semiaxes, rng=None):
+    """n points uniformly inside an axis-aligned ellipsoid (disimpy/simulations.py:385-399)."""
+    rng = rng or _host_rng(None)
+    return _rejection_sample(rng, n, 3, semiaxes, lambda p: np.sum((p / semiaxes) ** 2, axis=1) < 1)
+
+
+def _initial_positions_cylinder(n_walkers, radius, R, rng=None):
+    """Points in the (y, z) disc of the cylinder frame, rotated by R (disimpy/simulations.py:402-409)."""
+    positions = np.zeros((n_walkers, 3))
+    positions[:, 1:3] = _fill_circle(n_walkers, radius, rng)
+    return np.matmul(R, positions.T).T
+
+
+def _initial_positions_ellipsoid(n_walkers, semiaxes, R, rng=None):
+    """Points in the ellipsoid frame rotated by R (disimpy/simulations.py:412-418)."""
+    return np.matmul(R, _fill_ellipsoid(n_walkers, semiaxes, rng).T).T
+
+
+def _strip_wall_triangles(substrate):
+    """Mesh arrays without the 12 voxel-boundary triangles of a non-periodic
+    substrate, as ``_fill_mesh`` builds them (disimpy/simulations.py:531-542).
+
+    The reference deletes the wall references one by one and, for every
+    deletion at (current) position q, decrements BOTH ends of every subvoxel
+    whose end is > q.  That is equivalent to shifting the whole range of
+    subvoxel j down by d_j = number of deleted references located before its
+    original end, then clamping negatives to 0 (a subvoxel that contained a
+    deleted reference therefore also starts one reference early - a quirk of
+    the reference that is reproduced here because it decides which candidate
+    triangles the fill kernel visits)."""
+    vertices = np.copy(substrate.vertices[0:-8])
+    faces = np.copy(substrate.faces[0:-12])
+    tri = np.asarray(substrate.triangle_indices)
+    svi = np.array(substrate.subvoxel_indices, dtype=np.int64)
+    deleted = np.where(tri >= len(faces))[0]
+    d = np.searchsorted(deleted, svi[:, 1], side="left")
+    svi = svi - d[:, np.newaxis]
+    svi[svi < 0] = 0
+    return vertices, faces, np.delete(tri, deleted), svi
+
+
+def _fill_mesh(n_points, substrate, intra, seed, cuda_bs=128, device=0):
+    """Sample points uniformly inside (``intra``) or outside the closed surface of
+    a triangular mesh on the GPU (disimpy/simulations.py:505-579)."""
+    if substrate.periodic:
+        vertices, faces = substrate.vertices, substrate.faces
+        tri, svi = substrate.triangle_indices, substrate.subvoxel_indices
+    else:
+        vertices, faces, tri, svi = _strip_wall_triangles(substrate)
+    return _lib.fill_mesh(
+        n_points, intra, seed, vertices, faces, substrate.voxel_size, substrate.xs, substrate.ys, substrate.zs,
+        substrate.n_sv, svi, tri, device=device,
+    )  # fmt: skip
+
+
+# ----------------------------------------------------------------------------
+# small host utilities (disimpy/simulations.py:1016-1048)
+# ----------------------------------------------------------------------------
+
+
+def add_noise_to_data(data, sigma, seed=None):
+    """Add Rician noise to data.
+
+    Parameters
+    ----------
+    data : numpy.ndarray
+    sigma : float
+        Standard deviation of noise in each channel.
+    seed : int, optional
+
+    Returns
+    -------
+    noisy_data : numpy.ndarray
+    """
+    if seed:
+        np.random.seed(seed)
+    real = np.random.normal(size=data.shape, scale=sigma, loc=0)
+    imag = np.random.normal(size=data.shape, scale=sigma, loc=0)
+    return np.abs(data + real + 1j * imag)
+
+
+def _write_traj(traj, mode, positions):
+    """Append one line of ``x y z x y z ...`` (shortest round-trip decimals) to the trajectories file."""
+    with open(traj, mode) as f:
+        f.write(" ".join(map(repr, positions.ravel().tolist())))
+        f.write(" \n")
+
+
+# ----------------------------------------------------------------------------
+# the driver
+# ----------------------------------------------------------------------------
+
+
+def _validate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, cuda_bs, max_iter):
+    """Argument checks of disimpy/simulations.py:1128-1153 (same messages)."""
+    if not isinstance(n_walkers, int) or n_walkers <= 0:
+        raise ValueError("Incorrect value (%s) for n_walkers" % n_walkers)
+    if not isinstance(diffusivity, float) or diffusivity <= 0:
+        raise ValueError("Incorrect value (%s) for diffusivity" % diffusivity)
+    if (
+        not isinstance(gradient, np.ndarray)
+        or gradient.ndim != 3
+        or gradient.shape[2] != 3
+        or not np.issubdtype(gradient.dtype, np.floating)
+    ):
+        raise ValueError("Incorrect value (%s) for gradient" % gradient)
+    if not isinstance(dt, float) or dt <= 0:
+        raise ValueError("Incorrect value (%s) for dt" % dt)
+    if not isinstance(substrate, substrates._Substrate):
+        raise ValueError("Incorrect value (%s) for substrate" % substrate)
+    if not isinstance(seed, int) or seed < 0:
+        raise ValueError("Incorrect value (%s) for seed" % seed)
+    if traj:
+        if not isinstance(traj, str):
+            raise ValueError("Incorrect value (%s) for traj" % traj)
+    if not isinstance(quiet, bool):
+        raise ValueError("Incorrect value (%s) for quiet" % quiet)
+    if not isinstance(cuda_bs, int) or cuda_bs <= 0:
+        raise ValueError("Incorrect value (%s) for cuda_bs" % cuda_bs)
+    if not isinstance(max_iter, int) or max_iter < 1:
+        raise ValueError("Incorrect value (%s) for max_iter" % max_iter)
+
+
+def _initial_positions(n_walkers, substrate, seed, quiet, device):
+    """Initial positions of ALL walkers (global index order) and the per-substrate
+    launch closure.  Returns (positions or None for zeros, run(sim, t0, t1))."""
+    kind = substrate.type
+    if kind == "free":
+        return None, None
+    if kind == "cylinder":
+        R = utils.vec2vec_rotmat(substrate.orientation, np.array([1.0, 0, 0]))
+        R_inv = np.linalg.inv(R)
+        pos = _initial_positions_cylinder(n_walkers, substrate.radius, R_inv, _host_rng(seed))
+        return pos, (R, R_inv)
+    if kind == "sphere":
+        return _fill_sphere(n_walkers, substrate.radius, _host_rng(seed)), None
+    if kind == "ellipsoid":
+        R_inv = substrate.R
+        R = np.linalg.inv(R_inv)
+        pos = _initial_positions_ellipsoid(n_walkers, substrate.semiaxes, R_inv, _host_rng(seed))
+        return pos, (R, R_inv)
+    if kind == "mesh":
+        if isinstance(substrate.init_pos, np.ndarray):
+            if n_walkers != substrate.init_pos.shape[0]:
+                raise ValueError("n_walkers must be equal to the number of initial positions")
+            return substrate.init_pos, None
+        if not quiet:
+            print("Calculating initial positions")
+        if substrate.init_pos == "uniform":
+            pos = np.random.random((n_walkers, 3)) * substrate.voxel_size
+        elif substrate.init_pos == "intra":
+            pos = _fill_mesh(n_walkers, substrate, True, seed, device=device)
+        else:
+            pos = _fill_mesh(n_walkers, substrate, False, seed, device=device)
+        if not quiet:
+            print("Finished calculating initial positions")
+        return pos, None
+    raise ValueError("Incorrect value (%s) for substrate" % substrate)
+
+
+def _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1):
+    kind = substrate.type
+    if kind == "free":
+        sim.run_free(t0, t1)
+    elif kind == "sphere":
+        sim.run_sphere(substrate.radius, max_iter, epsilon, t0, t1)
+    elif kind == "cylinder":
+        sim.run_cylinder(substrate.radius, frames[0], frames[1], max_iter, epsilon, t0, t1)
+    elif kind == "ellipsoid":
+        sim.run_ellipsoid(substrate.semiaxes, frames[0], frames[1], max_iter, epsilon, t0, t1)
+    else:
+        sim.run_mesh(max_iter, epsilon, substrate.perm_prob, t0, t1)
+
+
+def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon, device=0,
+              walker_range=None, need_phases=False, need_positions=False):
+    """Run walkers [a, b) = ``walker_range`` (default: all) on one GPU.
+
+    Returns a dict with the device-reduced signal sums and, on request,
+    per-walker outputs of this range.  Walker i always gets RNG state i and
+    initial position i, so any partition of the walkers gives the same
+    per-walker results."""
+    n_t = gradient.shape[1]
+    a, b = (0, n_walkers) if walker_range is None else walker_range
+    step_l = np.sqrt(6 * diffusivity * dt)
+    if not quiet:
+        print("Number of random walkers = %s" % n_walkers)
+        print("Number of steps = %s" % n_t)
+        print("Step length = %s m" % step_l)
+        print("Step duration = %s s" % dt)
+    positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device)
+    with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a) as sim:
+        sim.rng_init_device(seed)
+        if positions is not None:
+            sim.set_positions(np.ascontiguousarray(positions[a:b], dtype=np.float64))
+        if substrate.type == "mesh":
+            sim.set_mesh(substrate.vertices, substrate.faces, substrate.xs, substrate.ys, substrate.zs,
+                         substrate.n_sv, substrate.subvoxel_indices, substrate.triangle_indices)
+        if traj:
+            _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions[a:b]))
+        if traj:
+            chunk = 1  # the trajectories file needs the positions after every step
+        elif quiet:
+            chunk = n_t
+        else:
+            chunk = max(1, int(math.ceil(n_t / 100)))  # progress is reported at range boundaries
+        ms_total = 0.0
+        for t0 in range(0, n_t, chunk):
+            t1 = min(n_t, t0 + chunk)
+            _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1)
+            ms_total += sim.last_run_ms()[0]
+            if traj:
+                _write_traj(traj, "a", sim.positions())
+            if not quiet:
+                sys.stdout.write(f"\r{np.round((t0 / n_t) * 100, 1)}%")
+                sys.stdout.flush()
+        out = {"device_ms": ms_total, "range": (a, b)}
+        out["cos"], out["sin"], out["n_exceeded"] = sim.signal()
+        out["iter_exc"] = sim.iter_exc() if (out["n_exceeded"] or need_phases) else np.zeros(b - a, dtype=bool)
+        if need_phases:
+            out["phases"] = sim.phases()
+        if need_positions:
+            out["positions"] = sim.positions()
+    return out
+
+
+def simulation(
+    n_walkers,
+    diffusivity,
+    gradient,
+    dt,
+    substrate,
+    seed=123,
+    traj=None,
+    final_pos=False,
+    all_signals=False,
+    quiet=False,
+    cuda_bs=128,
+    max_iter=int(1e3),
+    epsilon=1e-13,
+):
+    """Simulate a diffusion-weighted MR experiment and generate signal.
+
+    Same contract as ``disimpy.simulations.simulation``.
+
+    Parameters
+    ----------
+    n_walkers : int
+        Number of random walkers.
+    diffusivity : float
+        Diffusivity in SI units (m^2/s).
+    gradient : numpy.ndarray
+        Floating-point array of shape (number of measurements, number of time
+        points, 3), in T/m.
+    dt : float
+        Duration of a time step in the gradient array (s).
+    substrate : disimpy_amd.substrates._Substrate
+    seed : int, optional
+        Seed for pseudorandom number generation.
+    traj : str, optional
+        Path of a file in which to save the walker trajectories (one line per
+        time point: walker_1_x walker_1_y walker_1_z walker_2_x ...).
+    final_pos : bool, optional
+        If True, return ``(signal, final positions)``.
+    all_signals : bool, optional
+        If True, return the signal of every walker, shape (measurements, walkers).
+    quiet : bool, optional
+    cuda_bs : int, optional
+        Accepted for compatibility.  (In the reference it only changes how many
+        RNG states are created, never which state a walker uses.)
+    max_iter : int, optional
+        Maximum number of reflections checked per walker and time step.
+    epsilon : float, optional
+        Distance by which a walker is moved off a surface after a collision.
+
+    Returns
+    -------
+    signal : numpy.ndarray
+        Sum over walkers of cos(phase) per measurement (not divided by n_walkers).
+    """
+    try:
+        n_gpu = _lib.device_count()
+    except Exception as e:  # library missing / not loadable
+        raise Exception(_NO_GPU_MESSAGE + " (%s)" % e)
+    if n_gpu <= 0:
+        raise Exception(_NO_GPU_MESSAGE)
+    _validate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, cuda_bs, max_iter)
+    if not quiet:
+        print("Starting simulation")
+        if traj:
+            print("The trajectories file will be up to %s GB" % (gradient.shape[1] * n_walkers * 3 * 25 / 1e9))
+    np.random.seed(seed)  # the reference seeds the global NumPy generator too (:1169)
+    res = _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon,
+                    need_phases=bool(all_signals), need_positions=bool(final_pos))
+    iter_exc = res["iter_exc"]
+    if np.any(iter_exc):
+        warnings.warn(
+            "Maximum number of iterations was exceeded in the intersection "
+            + "check algorithm for walkers %s" % np.where(iter_exc)[0]
+        )
+    if all_signals:
+        phases = res["phases"]
+        phases[:, np.where(iter_exc)[0]] = np.nan
+        signals = np.real(np.exp(1j * phases))
+    else:
+        signals = res["cos"]
+    if not quiet:
+        sys.stdout.write("\rSimulation finished\n")
+        sys.stdout.flush()
+    if final_pos:
+        return signals, res["positions"]
+    return signals

@@ -1,0 +1,155 @@
+/* dsim.h - C ABI of the MI355X-native Monte Carlo diffusion-MRI hot path.
+ *
+ * The reference (kerkelae/disimpy) has no C ABI: its device boundary is Numba's
+ * `kernel[gs, bs, stream](*args)` launch inside disimpy/simulations.py
+ * simulation() (:1051-1429).  Each entry point below names the reference lines
+ * it replaces; together they are exactly what a ctypes binding inside
+ * simulation() needs (see INTEGRATION.md for that binding).
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function
+ * returns DSIM_OK (0) or a negative error code and never throws; after a
+ * failure dsim_last_error() returns a message (thread-local).  All functions
+ * block the calling host thread until the work is done.  Host buffers are
+ * caller-owned; device memory is library-owned behind the opaque handle.
+ * Layouts follow the reference: positions (N,3) row-major float64, phases
+ * (M,N) float64, gradient components (M,T) float64 each, RNG states
+ * {uint64 s0, uint64 s1} per walker, mesh index arrays int64.  Inside the
+ * library everything is re-laid-out SoA for coalesced HBM access.
+ */
+#ifndef DSIM_H
+#define DSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSIM_OK 0
+#define DSIM_ERR_INVALID (-1)   /* bad argument                                   */
+#define DSIM_ERR_NO_DEVICE (-2) /* no usable AMD GPU (reference: simulations.py:1116-1125) */
+#define DSIM_ERR_HIP (-3)       /* a HIP runtime call failed                      */
+#define DSIM_ERR_STATE (-4)     /* call order violated (e.g. run before set_mesh) */
+
+typedef struct dsim_sim *dsim_handle;
+
+/* Library version of this ABI (bumped on any signature change). */
+int dsim_abi_version(void);
+
+/* Message for the most recent failure on this thread ("" if none). */
+const char *dsim_last_error(void);
+
+/* Number of visible HIP devices; 0 when there is none.
+ * Replaces: cuda.detect() at simulations.py:1116-1125. */
+int dsim_device_count(void);
+
+/* Host-side RNG state creation, bit-faithful to
+ * numba.cuda.random.create_xoroshiro128p_states(n, seed) (call sites
+ * simulations.py:524, :1171): state 0 = splitmix64(seed) in both words, state
+ * i = state i-1 jumped 2^64 draws.  Writes the states of the global walker
+ * indices [first_index, first_index + n) as n pairs {s0, s1} into out (2n
+ * uint64).  Sequential in the index (128 draws per state), like the reference. */
+int dsim_rng_init(uint64_t seed, uint64_t first_index, uint64_t n, uint64_t *out_states);
+
+/* Same states, computed on the device in parallel with precomputed GF(2) jump
+ * matrices and left in the handle (no host round trip). */
+int dsim_rng_init_device(dsim_handle h, uint64_t seed);
+
+/* Create a simulation of n_walkers walkers whose global indices start at
+ * first_walker (multi-GPU sharding: walker i always uses RNG state i and
+ * initial position i), M measurements and T time points.
+ * gx, gy, gz: (M,T) row-major, the contiguous gradient[:, :, k] of
+ * simulations.py:1174-1176.  step_l = sqrt(6*D*dt) (:1181).  Allocates
+ * phases = 0 (:1177) and iter_exc = false (:1178), positions = 0.
+ * RNG states are NOT initialised: call dsim_rng_init_device or dsim_set_rng_states. */
+int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int64_t first_walker, int32_t M, int32_t T,
+                const double *gx, const double *gy, const double *gz, double dt, double step_l);
+
+int dsim_destroy(dsim_handle h);
+
+/* Initial positions, (n_walkers,3) row-major (cuda.to_device(positions), e.g. :1195). */
+int dsim_set_positions(dsim_handle h, const double *positions_aos);
+
+/* Upload RNG states produced by dsim_rng_init: n_walkers pairs {s0,s1}. */
+int dsim_set_rng_states(dsim_handle h, const uint64_t *states);
+
+/* Triangle mesh + voxelised triangle index of substrates._Substrate
+ * (substrates.py:24-42; uploads at simulations.py:1358-1365).  vertices
+ * (n_vertices,3) f64, faces (n_faces,3) i64, xs/ys/zs subvoxel boundaries of
+ * length n_sv[k]+1, subvoxel_indices (prod(n_sv),2) i64 [start,end) into
+ * triangle_indices (n_refs) i64.  The library rebuilds a compact device index
+ * (int32 CSR + pre-gathered {A, B-A, C-A} triangle records) with identical
+ * membership. */
+int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                  const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                  const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs);
+
+/* Advance all walkers over time steps [t_begin, t_end) in ONE fused launch per
+ * block of measurements (the reference launches one kernel per time step).
+ * Each replaces the per-step launch loop named beside it. */
+int dsim_run_free(dsim_handle h, int32_t t_begin, int32_t t_end); /* _cuda_step_free, :1198-1210 */
+int dsim_run_sphere(dsim_handle h, double radius, int64_t max_iter, double epsilon, int32_t t_begin,
+                    int32_t t_end); /* _cuda_step_sphere, :1268-1284 */
+int dsim_run_cylinder(dsim_handle h, double radius, const double R[9], const double R_inv[9], int64_t max_iter,
+                      double epsilon, int32_t t_begin, int32_t t_end); /* _cuda_step_cylinder, :1233-1251 */
+int dsim_run_ellipsoid(dsim_handle h, const double semiaxes[3], const double R[9], const double R_inv[9],
+                       int64_t max_iter, double epsilon, int32_t t_begin,
+                       int32_t t_end); /* _cuda_step_ellipsoid, :1308-1326 */
+int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, double perm_prob, int32_t t_begin,
+                  int32_t t_end); /* _cuda_step_mesh, :1369-1393 (without the 10 ms sleep of :1394) */
+
+/* Signal assembly on the device (replaces the D2H of the (M,N) phase matrix and
+ * the host numpy reduction of simulations.py:1406-1421): out_cos[m] = sum of
+ * cos(phase[m,i]), out_sin[m] = sum of sin(phase[m,i]) over walkers that did
+ * not exceed max_iter and whose phase is not NaN (nansum semantics);
+ * n_exceeded = number of walkers with iter_exc set.  out_sin / n_exceeded may
+ * be NULL. */
+int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_exceeded);
+
+/* Per-walker outputs for final_pos / traj / all_signals / the warning text. */
+int dsim_get_positions(dsim_handle h, double *positions_aos);        /* (n_walkers,3), :1212, :1426 */
+int dsim_get_phases(dsim_handle h, double *phases);                  /* (M,n_walkers), :1415          */
+int dsim_get_iter_exc(dsim_handle h, uint8_t *iter_exc);             /* (n_walkers,), :1406           */
+int dsim_get_rng_states(dsim_handle h, uint64_t *states);            /* n_walkers pairs               */
+
+/* Initial positions inside ('intra' != 0) or outside the surface: the whole
+ * _fill_mesh loop of simulations.py:505-579 (own RNG states from `seed`,
+ * repeated _cuda_fill_mesh launches over n_points threads until n_points
+ * points were accepted, accepted points kept in thread order).  The mesh
+ * arrays are the ones the reference uploads there (wall triangles already
+ * stripped for non-periodic substrates).  out: (n_points,3). */
+int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const double *vertices,
+                   int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double voxel_size[3],
+                   const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                   const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs,
+                   double *out_points);
+
+/* Voxelised triangle index on the host (substrates.py:467-536,
+ * _mesh_space_subdivision; the boundaries xs/ys/zs of :506-508 are passed in).
+ * Call with triangle_indices == NULL to get the number of references in
+ * *n_refs, then again with a buffer of that size.  subvoxel_indices:
+ * (prod(n_sv),2) i64.  Needs no GPU. */
+int dsim_mesh_subdivide(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                        const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                        int64_t *subvoxel_indices, int64_t *triangle_indices, int64_t *n_refs);
+
+/* The two predicates dsim_mesh_subdivide is built from, exported for unit tests
+ * that mirror disimpy/tests/test_substrates.py:293-345: triangle (3,3) vs box
+ * (2,3) overlap (substrates.py:291-368; returns 1/0), and the subvoxel index
+ * range [ll, ul) overlapped by the interval [x1, x2] (substrates.py:371-419). */
+int dsim_triangle_box_overlap(const double triangle[9], const double box[6]);
+int dsim_interval_sv_overlap(const double *xs, int64_t n_xs, double x1, double x2, int64_t *ll, int64_t *ul);
+
+/* Measurement hooks used by bench.py: device time (HIP events on the library's
+ * own stream) of the most recent dsim_run_* call in milliseconds, the number of
+ * kernel launches it made, and the name of the kernel. */
+int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
+
+/* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
+ * LDS gradient tile, measurements held in registers per pass. */
+int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSIM_H */

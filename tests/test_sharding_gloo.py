@@ -1,0 +1,89 @@
+"""Multi-process path on CPU: world_size-2 `gloo` group.  The shard partition,
+the global-index RNG convention and the signal all-reduce are exercised with
+the CPU oracle standing in for the GPU kernels (tests may use the oracle as the
+compute engine; the product never does)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_all_walkers():
+    from disimpy_amd.sharding import shard_range
+
+    for n in (1, 7, 1000, 10**7 + 3):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for (a0, b0), (a1, b1) in zip(ranges[:-1], ranges[1:]):
+                assert b0 == a1 and a0 <= b0
+            per = -(-n // world)
+            assert all(b - a <= per for a, b in ranges)
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disimpy_amd import gradients, sharding
+    from oracle.oracle import FREE, Oracle
+
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 60, np.array([1e9, 5e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    step_l = float(np.sqrt(6 * 2e-9 * dt))
+    o = Oracle(exact=False)
+    a, b = sharding.shard_range(n, rank, world)
+    st = o.rng_states(b, 123)[a:].copy()  # walker i <- RNG state i, whatever the partition
+    pos = np.zeros((b - a, 3))
+    ph, exc, _ = o.run(o.geom(FREE), gradient, dt, step_l, pos, st)
+    c, s = o.signal(ph, exc)
+    tc, ts, nexc = sharding.reduce_signal(c, s, int(exc.sum()), dist)
+    q.put((rank, tc, ts, nexc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_reduce_matches_single_process():
+    from disimpy_amd import gradients
+    from oracle.oracle import FREE, Oracle
+
+    n, world = 1001, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 60, np.array([1e9, 5e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    step_l = float(np.sqrt(6 * 2e-9 * dt))
+    o = Oracle(exact=False)
+    st = o.rng_states(n, 123)
+    pos = np.zeros((n, 3))
+    ph, exc, _ = o.run(o.geom(FREE), gradient, dt, step_l, pos, st)
+    c, s = o.signal(ph, exc)
+    for rank, tc, ts, nexc in got:
+        np.testing.assert_allclose(tc, c, rtol=0, atol=1e-12 * n)  # summation order only
+        np.testing.assert_allclose(ts, s, rtol=0, atol=1e-12 * n)
+        assert nexc == 0
+    np.testing.assert_array_equal(got[0][1], got[1][1])  # every rank holds the same total
