@@ -210,7 +210,7 @@ struct dsim_sim {
   double *phase = nullptr;
   uint8_t *exc = nullptr;
   double *g4 = nullptr;
-  double *partial = nullptr, *sig_out = nullptr;
+  double *partial = nullptr, *nexc_partial = nullptr, *sig_out = nullptr;
   int sig_blocks = 0;
   void *staging = nullptr;
   size_t staging_bytes = 0;
@@ -252,6 +252,7 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->exc) (void)hipFree(h->exc);
   if (h->g4) (void)hipFree(h->g4);
   if (h->partial) (void)hipFree(h->partial);
+  if (h->nexc_partial) (void)hipFree(h->nexc_partial);
   if (h->sig_out) (void)hipFree(h->sig_out);
   if (h->staging) (void)hipFree(h->staging);
   free_mesh(h->mesh);
@@ -298,6 +299,7 @@ static int create_impl(dsim_sim *h, const double *gx, const double *gy, const do
   HIP_TRY(hipMemcpyAsync(h->g4, g4.data(), g4.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   h->sig_blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
   HIP_TRY(hipMalloc(&h->partial, (size_t)h->M * h->sig_blocks * 2 * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->nexc_partial, (size_t)h->sig_blocks * sizeof(double)));
   HIP_TRY(hipMalloc(&h->sig_out, (size_t)(2 * h->M + 1) * sizeof(double)));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return DSIM_OK;
@@ -430,9 +432,9 @@ extern "C" int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, 
   if (!h || !out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
   HIP_TRY(hipSetDevice(h->device));
   dim3 grid(h->sig_blocks, h->M);
-  signal_partial_kernel<<<grid, 256, 0, h->stream>>>(h->phase, h->exc, h->n, h->partial);
+  signal_partial_kernel<<<grid, 256, 0, h->stream>>>(h->phase, h->exc, h->n, h->partial, h->nexc_partial);
   HIP_TRY(hipGetLastError());
-  signal_final_kernel<<<h->M + 1, 64, 0, h->stream>>>(h->partial, h->sig_blocks, h->exc, h->n, h->M, h->sig_out);
+  signal_final_kernel<<<h->M + 1, 64, 0, h->stream>>>(h->partial, h->nexc_partial, h->sig_blocks, h->M, h->sig_out);
   HIP_TRY(hipGetLastError());
   std::vector<double> out((size_t)2 * h->M + 1);
   HIP_TRY(hipMemcpyAsync(out.data(), h->sig_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

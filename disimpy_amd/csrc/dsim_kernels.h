@@ -313,17 +313,20 @@ DSD double wave_sum(double v) {
   return v;
 }
 
-/* grid = (blocks, M); partial[(m*gridDim.x + b)*2 + {0,1}] = block sums of cos, sin.
+/* grid = (blocks, M); partial[(m*gridDim.x + b)*2 + {0,1}] = block sums of cos, sin;
+ * the m == 0 row also counts the exceeded walkers into nexc_partial[b].
  * Replaces phases D2H + np.nansum(np.exp(1j*phases)) (simulations.py:1413-1421):
  * walkers with iter_exc set or a NaN phase contribute nothing. */
 __global__ __launch_bounds__(256) void signal_partial_kernel(const double *phase, const uint8_t *exc, int64_t n,
-                                                             double *partial) {
-  __shared__ double sc[4], ss[4];
+                                                             double *partial, double *nexc_partial) {
+  __shared__ double sc[4], ss[4], se[4];
   const int m = blockIdx.y;
-  double c = 0, s = 0;
+  double c = 0, s = 0, e = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double ph = phase[(int64_t)m * n + i];
-    if (exc[i] == 0 && ph == ph) {
+    const bool x = exc[i] != 0;
+    e += x ? 1.0 : 0.0;
+    if (!x && ph == ph) {
       double sv, cv;
       sincos(ph, &sv, &cv);
       if (sv == sv && cv == cv) {
@@ -334,27 +337,31 @@ __global__ __launch_bounds__(256) void signal_partial_kernel(const double *phase
   }
   c = wave_sum(c);
   s = wave_sum(s);
+  e = wave_sum(e);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
     sc[wave] = c;
     ss[wave] = s;
+    se[wave] = e;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double tc = 0, ts = 0;
+    double tc = 0, ts = 0, te = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
       tc += sc[w];
       ts += ss[w];
+      te += se[w];
     }
     partial[((int64_t)m * gridDim.x + blockIdx.x) * 2] = tc;
     partial[((int64_t)m * gridDim.x + blockIdx.x) * 2 + 1] = ts;
+    if (m == 0) nexc_partial[blockIdx.x] = te;
   }
 }
 
 /* one wavefront per measurement folds the block partials in a fixed order
- * (deterministic, no float atomics); block M counts the exceeded walkers. */
-__global__ __launch_bounds__(64) void signal_final_kernel(const double *partial, int n_blocks, const uint8_t *exc,
-                                                          int64_t n, int M, double *out /* [2M + 1] */) {
+ * (deterministic, no float atomics); block M folds the exceeded-walker counts. */
+__global__ __launch_bounds__(64) void signal_final_kernel(const double *partial, const double *nexc_partial, int n_blocks,
+                                                          int M, double *out /* [2M + 1] */) {
   const int m = blockIdx.x;
   if (m < M) {
     double c = 0, s = 0;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(64) void signal_final_kernel(const double *partial,
     }
   } else {
     double cnt = 0;
-    for (int64_t i = threadIdx.x; i < n; i += 64) cnt += exc[i] ? 1.0 : 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 64) cnt += nexc_partial[b];
     cnt = wave_sum(cnt);
     if (threadIdx.x == 0) out[2 * M] = cnt;
   }
