@@ -199,19 +199,34 @@ DSD int ul_subvoxel_overlap(const double *xs, int n, double inv_h, double xmax) 
   return i;
 }
 
-/* simulations.py:654-679 */
-DSD int ll_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, double x1, double x2) {
+/* floor(x / voxel) with the IEEE quotient of the reference (simulations.py:661,
+ * :675) but without paying an fp64 division on the common paths:
+ *  - 0 <= x < voxel: the correctly rounded quotient is in [0, 1), floor is 0;
+ *  - otherwise q = x * (1/voxel) is within 4 ulp of the IEEE quotient, so the
+ *    two floors can only differ when q lies within 1e-9 of an integer (for
+ *    |q| < 1e6); only then is the real division evaluated. */
+DSD double floor_quotient(double x, double voxel, double inv_voxel) {
+  if (x >= 0 && x < voxel) return 0.0;
+  double q = x * inv_voxel;
+  double k = __builtin_floor(q);
+  double f = q - k;
+  if (!(f > 1e-9 && f < 1.0 - 1e-9 && __builtin_fabs(q) < 1e6)) k = __builtin_floor(x / voxel);
+  return k;
+}
+
+/* simulations.py:654-679; inv_voxel = 1 / voxel is a first guess only */
+DSD int ll_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, double inv_voxel, double x1, double x2) {
   double xmin = x1 < x2 ? x1 : x2;
   double voxel = __builtin_fabs(xs[n] - xs[0]);
-  double k = __builtin_floor(xmin / voxel);
+  double k = floor_quotient(xmin, voxel, inv_voxel);
   double shifted = __builtin_fma(-k, voxel, xmin);
   return ll_subvoxel_overlap(xs, n, inv_h, shifted) + (int)k * n;
 }
 
-DSD int ul_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, double x1, double x2) {
+DSD int ul_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, double inv_voxel, double x1, double x2) {
   double xmax = x1 > x2 ? x1 : x2;
   double voxel = __builtin_fabs(xs[n] - xs[0]);
-  double k = __builtin_floor(xmax / voxel);
+  double k = floor_quotient(xmax, voxel, inv_voxel);
   double shifted = __builtin_fma(-k, voxel, xmax);
   return ul_subvoxel_overlap(xs, n, inv_h, shifted) + (int)k * n;
 }

@@ -191,9 +191,10 @@ struct DevMesh {
   double *tri = nullptr;
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
+  float4 *ref_box = nullptr;
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
-  double inv_h[3] = {0, 0, 0};
+  double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
   bool set = false;
 };
 
@@ -224,6 +225,7 @@ static void free_mesh(DevMesh &m) {
   if (m.tri) (void)hipFree(m.tri);
   if (m.sv_range) (void)hipFree(m.sv_range);
   if (m.tri_idx) (void)hipFree(m.tri_idx);
+  if (m.ref_box) (void)hipFree(m.ref_box);
   if (m.bounds) (void)hipFree(m.bounds);
   m = DevMesh();
 }
@@ -485,6 +487,23 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
     refs[i] = (int32_t)triangle_indices[i];
   }
+  /* per-reference cull records: float32 AABB rounded outward + triangle index */
+  std::vector<float4> boxes((size_t)std::max<int64_t>(n_refs, 1) * 2);
+  for (int64_t i = 0; i < n_refs; i++) {
+    const int64_t *fc = &faces[(size_t)refs[i] * 3];
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+      double a = vertices[fc[0] * 3 + k], b = vertices[fc[1] * 3 + k], c = vertices[fc[2] * 3 + k];
+      double mn = std::min(a, std::min(b, c)), mx = std::max(a, std::max(b, c));
+      lo[k] = std::nextafter((float)mn, -std::numeric_limits<float>::infinity());
+      hi[k] = std::nextafter((float)mx, std::numeric_limits<float>::infinity());
+    }
+    float idx_bits;
+    int32_t ti = refs[i];
+    memcpy(&idx_bits, &ti, sizeof(float));
+    boxes[2 * i] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+    boxes[2 * i + 1] = make_float4(hi[1], hi[2], idx_bits, 0.0f);
+  }
   std::vector<double> bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
   bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
@@ -492,6 +511,8 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&dm.ref_box, boxes.size() * sizeof(float4)));
+  HIP_TRY(hipMemcpyAsync(dm.ref_box, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
@@ -505,6 +526,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   for (int k = 0; k < 3; k++) {
     double L = b3[k][n_sv[k]] - b3[k][0];
     dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
+    dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
   }
   dm.set = true;
   return DSIM_OK;
@@ -515,6 +537,7 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.tri = dm.tri;
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
+  m.ref_box = dm.ref_box;
   m.bounds = dm.bounds;
   m.nx = dm.nx;
   m.ny = dm.ny;
@@ -522,6 +545,9 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.inv_hx = dm.inv_h[0];
   m.inv_hy = dm.inv_h[1];
   m.inv_hz = dm.inv_h[2];
+  m.inv_lx = dm.inv_l[0];
+  m.inv_ly = dm.inv_l[1];
+  m.inv_lz = dm.inv_l[2];
   return m;
 }
 

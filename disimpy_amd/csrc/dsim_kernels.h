@@ -22,9 +22,12 @@ struct MeshDev {
   const double *tri;       /* [n_faces][9]  {A, E1, E2}                  */
   const int2 *sv_range;    /* [prod n_sv]   [start, end) into tri_idx    */
   const int32_t *tri_idx;  /* [n_refs]                                   */
+  const float4 *ref_box;   /* [n_refs][2]   {minx miny minz maxx} {maxy maxz idx 0}: float32 AABB rounded
+                              outward + triangle index, in CSR order (one 32-byte record per reference) */
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
+  double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
 };
 
 struct WalkParams {
@@ -128,6 +131,34 @@ DSD V3 load_v3(const double *p) {
   return v;
 }
 
+/* Conservative cull box of the remaining segment r0 -> r0 + step*step_l, in
+ * float32.  A candidate triangle whose (outward-rounded) float32 AABB does not
+ * meet this box cannot return 0 < d <= step_l from the Moller-Trumbore test, so
+ * skipping it changes neither the decision `min_d > step_l` nor the closest
+ * triangle when there is a hit (simulations.py:981-986): results stay
+ * bit-identical to testing every candidate.  The margin (1e-6 step_l plus 2.4e-7
+ * of the coordinate, i.e. 4 float32 ulps) dwarfs every fp64 rounding error of
+ * the test itself (~1e-16 relative). */
+struct CullBox {
+  float lox, loy, loz, hix, hiy, hiz;
+};
+
+DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
+  V3 e = {__builtin_fma(step.x, step_l, a.x), __builtin_fma(step.y, step_l, a.y), __builtin_fma(step.z, step_l, a.z)};
+  const double ms = 1e-6 * step_l, mr = 2.4e-7;
+  double mx = ms + mr * __builtin_fmax(__builtin_fabs(a.x), __builtin_fabs(e.x));
+  double my = ms + mr * __builtin_fmax(__builtin_fabs(a.y), __builtin_fabs(e.y));
+  double mz = ms + mr * __builtin_fmax(__builtin_fabs(a.z), __builtin_fabs(e.z));
+  CullBox c;
+  c.lox = (float)(__builtin_fmin(a.x, e.x) - mx);
+  c.loy = (float)(__builtin_fmin(a.y, e.y) - my);
+  c.loz = (float)(__builtin_fmin(a.z, e.z) - mz);
+  c.hix = (float)(__builtin_fmax(a.x, e.x) + mx);
+  c.hiy = (float)(__builtin_fmax(a.y, e.y) + my);
+  c.hiz = (float)(__builtin_fmax(a.z, e.z) + mz);
+  return c;
+}
+
 /* simulations.py:878-1002.  xs/ys/zs: LDS copies of the subvoxel boundaries. */
 DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const double *xs, const double *ys,
                    const double *zs, Rng &rng, bool &exc) {
@@ -143,12 +174,12 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
     double ex = __builtin_fma(step.x, step_l, r0.x);
     double ey = __builtin_fma(step.y, step_l, r0.y);
     double ez = __builtin_fma(step.z, step_l, r0.z);
-    int llx = ll_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, r0.x, ex);
-    int lly = ll_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, r0.y, ey);
-    int llz = ll_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, r0.z, ez);
-    int ulx = ul_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, r0.x, ex);
-    int uly = ul_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, r0.y, ey);
-    int ulz = ul_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, r0.z, ez);
+    int llx = ll_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+    int lly = ll_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+    int llz = ll_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+    int ulx = ul_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+    int uly = ul_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+    int ulz = ul_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
     for (int xi = llx; xi < ulx; xi++) {
       int x = xi;
       double shx = 0;
@@ -174,10 +205,15 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
             shz = (double)sn * Lz;
           }
           int sv = (x * ny + y) * nz + z;
-          V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
           int2 range = ms.sv_range[sv];
+          if (range.x >= range.y) continue;
+          V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
+          const CullBox cb = make_cull_box(tr0, step, step_l);
           for (int i = range.x; i < range.y; i++) {
-            int ti = ms.tri_idx[i];
+            /* 32-byte reference record: float32 AABB of the triangle + its index */
+            const float4 b0 = ms.ref_box[2 * i], b1 = ms.ref_box[2 * i + 1];
+            if (b0.x > cb.hix || b0.w < cb.lox || b0.y > cb.hiy || b1.x < cb.loy || b0.z > cb.hiz || b1.y < cb.loz) continue;
+            int ti = __float_as_int(b1.z);
             const double *rec = ms.tri + (int64_t)ti * 9;
             double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
             if (d > 0 && d < min_d) {
