@@ -195,6 +195,7 @@ struct DevMesh {
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
   double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
+  int csr_contiguous = 0;
   bool set = false;
 };
 
@@ -482,6 +483,9 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (a < 0 || b < a || b > n_refs) return fail(DSIM_ERR_INVALID, "mesh: subvoxel %lld has a bad range", (long long)s);
     ranges[s] = make_int2((int)a, (int)b);
   }
+  int contiguous = 1;
+  for (int64_t s = 0; s + 1 < n_sub; s++)
+    if (ranges[s].y != ranges[s + 1].x) contiguous = 0;
   std::vector<int32_t> refs((size_t)std::max<int64_t>(n_refs, 1));
   for (int64_t i = 0; i < n_refs; i++) {
     if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
@@ -528,6 +532,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
     dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
   }
+  dm.csr_contiguous = contiguous;
   dm.set = true;
   return DSIM_OK;
 }
@@ -548,6 +553,7 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.inv_lx = dm.inv_l[0];
   m.inv_ly = dm.inv_l[1];
   m.inv_lz = dm.inv_l[2];
+  m.csr_contiguous = dm.csr_contiguous;
   return m;
 }
 

@@ -28,6 +28,7 @@ struct MeshDev {
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
   double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
+  int csr_contiguous;            /* sv_range[s].y == sv_range[s+1].x for all s */
 };
 
 struct WalkParams {
@@ -159,6 +160,37 @@ DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   return c;
 }
 
+/* Candidate scan of one contiguous slice of reference records: 4 records (128
+ * bytes) are requested before the first is examined, so that the L2 round trips
+ * of a slice overlap instead of queueing behind each other. */
+DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step,
+                         double &min_d, int &closest) {
+  for (int i = begin; i < end; i += 4) {
+    float4 b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int j = min(i + u, end - 1);
+      b0[u] = ms.ref_box[2 * j];
+      b1[u] = ms.ref_box[2 * j + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i + u >= end) break;
+      /* 32-byte reference record: float32 AABB of the triangle + its index */
+      if (b0[u].x > cb.hix || b0[u].w < cb.lox || b0[u].y > cb.hiy || b1[u].x < cb.loy || b0[u].z > cb.hiz ||
+          b1[u].y < cb.loz)
+        continue;
+      int ti = __float_as_int(b1[u].z);
+      const double *rec = ms.tri + (int64_t)ti * 9;
+      double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
+      if (d > 0 && d < min_d) {
+        closest = ti;
+        min_d = d;
+      }
+    }
+  }
+}
+
 /* simulations.py:878-1002.  xs/ys/zs: LDS copies of the subvoxel boundaries. */
 DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const double *xs, const double *ys,
                    const double *zs, Rng &rng, bool &exc) {
@@ -196,7 +228,12 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
           y -= sn * ny;
           shy = (double)sn * Ly;
         }
-        for (int zi = llz; zi < ulz; zi++) {
+        /* z is the fastest index of the CSR index, so the reference lists of a run of
+         * consecutive z subvoxels inside one periodic image are ONE contiguous slice
+         * of references: two range loads per (x, y) column instead of one per subvoxel.
+         * The candidates are visited in the same order as subvoxel by subvoxel. */
+        int zi = llz;
+        while (zi < ulz) {
           int z = zi;
           double shz = 0;
           if (z < 0 || z > nz - 1) {
@@ -204,23 +241,14 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
             z -= sn * nz;
             shz = (double)sn * Lz;
           }
+          int run = ms.csr_contiguous ? min(ulz - zi, nz - z) : 1;
+          zi += run;
           int sv = (x * ny + y) * nz + z;
-          int2 range = ms.sv_range[sv];
-          if (range.x >= range.y) continue;
+          int begin = ms.sv_range[sv].x, end = ms.sv_range[sv + run - 1].y;
+          if (begin >= end) continue;
           V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
           const CullBox cb = make_cull_box(tr0, step, step_l);
-          for (int i = range.x; i < range.y; i++) {
-            /* 32-byte reference record: float32 AABB of the triangle + its index */
-            const float4 b0 = ms.ref_box[2 * i], b1 = ms.ref_box[2 * i + 1];
-            if (b0.x > cb.hix || b0.w < cb.lox || b0.y > cb.hiy || b1.x < cb.loy || b0.z > cb.hiz || b1.y < cb.loz) continue;
-            int ti = __float_as_int(b1.z);
-            const double *rec = ms.tri + (int64_t)ti * 9;
-            double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
-            if (d > 0 && d < min_d) {
-              closest = ti;
-              min_d = d;
-            }
-          }
+          scan_candidates(ms, begin, end, cb, tr0, step, min_d, closest);
         }
       }
     }
