@@ -191,11 +191,11 @@ struct DevMesh {
   double *tri = nullptr;
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
-  float4 *ref_box = nullptr;
+  float4 *mrec = nullptr;
+  int2 *sv_micro = nullptr, *cell_range = nullptr;
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
   double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
-  int csr_contiguous = 0;
   bool set = false;
 };
 
@@ -226,7 +226,9 @@ static void free_mesh(DevMesh &m) {
   if (m.tri) (void)hipFree(m.tri);
   if (m.sv_range) (void)hipFree(m.sv_range);
   if (m.tri_idx) (void)hipFree(m.tri_idx);
-  if (m.ref_box) (void)hipFree(m.ref_box);
+  if (m.mrec) (void)hipFree(m.mrec);
+  if (m.sv_micro) (void)hipFree(m.sv_micro);
+  if (m.cell_range) (void)hipFree(m.cell_range);
   if (m.bounds) (void)hipFree(m.bounds);
   m = DevMesh();
 }
@@ -483,30 +485,84 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (a < 0 || b < a || b > n_refs) return fail(DSIM_ERR_INVALID, "mesh: subvoxel %lld has a bad range", (long long)s);
     ranges[s] = make_int2((int)a, (int)b);
   }
-  int contiguous = 1;
-  for (int64_t s = 0; s + 1 < n_sub; s++)
-    if (ranges[s].y != ranges[s + 1].x) contiguous = 0;
+
   std::vector<int32_t> refs((size_t)std::max<int64_t>(n_refs, 1));
   for (int64_t i = 0; i < n_refs; i++) {
     if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
     refs[i] = (int32_t)triangle_indices[i];
   }
-  /* per-reference cull records: float32 AABB rounded outward + triangle index */
-  std::vector<float4> boxes((size_t)std::max<int64_t>(n_refs, 1) * 2);
-  for (int64_t i = 0; i < n_refs; i++) {
-    const int64_t *fc = &faces[(size_t)refs[i] * 3];
-    float lo[3], hi[3];
+  /* Micro-grids.  The reference's candidate set of a subvoxel is its whole list
+   * (up to 88 triangles per 4.3 um subvoxel on the neuron, several subvoxels per
+   * step), and a wavefront pays for its worst lane.  Every reference subvoxel
+   * with more than 8 references is therefore cut into k^3 micro-cells (k = 2, 4,
+   * 8); cell c holds the references of THIS subvoxel whose float32 AABB (rounded
+   * outward, clamped into the subvoxel) reaches c.  A query visits the cells
+   * reached by the segment's cull box (same clamped, monotone cell map), i.e. a
+   * subset of the reference's list that still contains every triangle whose AABB
+   * meets the cull box - the same exactness argument as make_cull_box(). Each
+   * 32-byte record = float32 AABB + triangle index + CSR position (tie order). */
+  double inv_h3[3];
+  {
+    const double *b3[3] = {xs, ys, zs};
     for (int k = 0; k < 3; k++) {
-      double a = vertices[fc[0] * 3 + k], b = vertices[fc[1] * 3 + k], c = vertices[fc[2] * 3 + k];
-      double mn = std::min(a, std::min(b, c)), mx = std::max(a, std::max(b, c));
-      lo[k] = std::nextafter((float)mn, -std::numeric_limits<float>::infinity());
-      hi[k] = std::nextafter((float)mx, std::numeric_limits<float>::infinity());
+      double L = b3[k][n_sv[k]] - b3[k][0];
+      inv_h3[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
     }
-    float idx_bits;
-    int32_t ti = refs[i];
-    memcpy(&idx_bits, &ti, sizeof(float));
-    boxes[2 * i] = make_float4(lo[0], lo[1], lo[2], hi[0]);
-    boxes[2 * i + 1] = make_float4(hi[1], hi[2], idx_bits, 0.0f);
+  }
+  std::vector<int2> sv_micro((size_t)n_sub);
+  std::vector<int2> cell_range;
+  std::vector<float4> mrec;
+  cell_range.push_back(make_int2(0, 0)); /* cell 0: shared by all empty subvoxels */
+  {
+    std::vector<std::vector<int32_t>> cells;
+    std::vector<float> lo3, hi3;
+    for (int64_t s = 0; s < n_sub; s++) {
+      const int begin = ranges[s].x, end = ranges[s].y, n_s = end - begin;
+      if (n_s <= 0) {
+        sv_micro[s] = make_int2(0, 0);
+        continue;
+      }
+      const int lk = n_s <= 8 ? 0 : (n_s <= 32 ? 1 : (n_s <= 128 ? 2 : 3));
+      const int k = 1 << lk;
+      const int64_t sx = s / (n_sv[1] * n_sv[2]), sy = (s / n_sv[2]) % n_sv[1], sz = s % n_sv[2];
+      const double org[3] = {xs[sx], ys[sy], zs[sz]};
+      const double scale[3] = {(double)k * inv_h3[0], (double)k * inv_h3[1], (double)k * inv_h3[2]};
+      cells.assign((size_t)k * k * k, std::vector<int32_t>());
+      lo3.assign((size_t)n_s * 3, 0.f);
+      hi3.assign((size_t)n_s * 3, 0.f);
+      for (int i = begin; i < end; i++) {
+        const int64_t *fc = &faces[(size_t)refs[i] * 3];
+        int c0[3], c1[3];
+        for (int ax = 0; ax < 3; ax++) {
+          double a = vertices[fc[0] * 3 + ax], b = vertices[fc[1] * 3 + ax], c = vertices[fc[2] * 3 + ax];
+          double mn = std::min(a, std::min(b, c)), mx = std::max(a, std::max(b, c));
+          float lo = std::nextafter((float)mn, -std::numeric_limits<float>::infinity());
+          float hi = std::nextafter((float)mx, std::numeric_limits<float>::infinity());
+          lo3[(size_t)(i - begin) * 3 + ax] = lo;
+          hi3[(size_t)(i - begin) * 3 + ax] = hi;
+          c0[ax] = micro_cell((double)lo, org[ax], scale[ax], k);
+          c1[ax] = micro_cell((double)hi, org[ax], scale[ax], k);
+        }
+        for (int a = c0[0]; a <= c1[0]; a++)
+          for (int b = c0[1]; b <= c1[1]; b++)
+            for (int c = c0[2]; c <= c1[2]; c++) cells[((size_t)a * k + b) * k + c].push_back(i);
+      }
+      sv_micro[s] = make_int2((int)cell_range.size(), lk);
+      for (auto &cl : cells) {
+        int start = (int)(mrec.size() / 2);
+        for (int32_t i : cl) {
+          const float *lo = &lo3[(size_t)(i - begin) * 3], *hi = &hi3[(size_t)(i - begin) * 3];
+          float idx_bits, pos_bits;
+          int32_t ti = refs[i];
+          memcpy(&idx_bits, &ti, sizeof(float));
+          memcpy(&pos_bits, &i, sizeof(float));
+          mrec.push_back(make_float4(lo[0], lo[1], lo[2], hi[0]));
+          mrec.push_back(make_float4(hi[1], hi[2], idx_bits, pos_bits));
+        }
+        cell_range.push_back(make_int2(start, (int)(mrec.size() / 2)));
+      }
+    }
+    if (mrec.empty()) mrec.resize(2, make_float4(0, 0, 0, 0));
   }
   std::vector<double> bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
@@ -515,8 +571,12 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&dm.ref_box, boxes.size() * sizeof(float4)));
-  HIP_TRY(hipMemcpyAsync(dm.ref_box, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMalloc(&dm.mrec, mrec.size() * sizeof(float4)));
+  HIP_TRY(hipMalloc(&dm.sv_micro, sv_micro.size() * sizeof(int2)));
+  HIP_TRY(hipMalloc(&dm.cell_range, cell_range.size() * sizeof(int2)));
+  HIP_TRY(hipMemcpyAsync(dm.mrec, mrec.data(), mrec.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.sv_micro, sv_micro.data(), sv_micro.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.cell_range, cell_range.data(), cell_range.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
@@ -532,7 +592,6 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
     dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
   }
-  dm.csr_contiguous = contiguous;
   dm.set = true;
   return DSIM_OK;
 }
@@ -542,7 +601,9 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.tri = dm.tri;
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
-  m.ref_box = dm.ref_box;
+  m.mrec = dm.mrec;
+  m.sv_micro = dm.sv_micro;
+  m.cell_range = dm.cell_range;
   m.bounds = dm.bounds;
   m.nx = dm.nx;
   m.ny = dm.ny;
@@ -553,7 +614,6 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.inv_lx = dm.inv_l[0];
   m.inv_ly = dm.inv_l[1];
   m.inv_lz = dm.inv_l[2];
-  m.csr_contiguous = dm.csr_contiguous;
   return m;
 }
 

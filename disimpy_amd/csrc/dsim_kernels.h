@@ -14,6 +14,8 @@
 #ifndef DSIM_KERNELS_H
 #define DSIM_KERNELS_H
 
+#include <limits.h>
+
 #include "dsim_device.h"
 
 enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };
@@ -22,13 +24,14 @@ struct MeshDev {
   const double *tri;       /* [n_faces][9]  {A, E1, E2}                  */
   const int2 *sv_range;    /* [prod n_sv]   [start, end) into tri_idx    */
   const int32_t *tri_idx;  /* [n_refs]                                   */
-  const float4 *ref_box;   /* [n_refs][2]   {minx miny minz maxx} {maxy maxz idx 0}: float32 AABB rounded
-                              outward + triangle index, in CSR order (one 32-byte record per reference) */
+  const int2 *sv_micro;    /* [prod n_sv]   {first cell, log2 k}: micro-grid of the subvoxel        */
+  const int2 *cell_range;  /* [n_cells]     [start, end) into mrec                                  */
+  const float4 *mrec;      /* [n_mrec][2]   {minx miny minz maxx} {maxy maxz tri csr_pos}: float32 AABB
+                              rounded outward + triangle index + position in the reference's list */
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
   double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
-  int csr_contiguous;            /* sv_range[s].y == sv_range[s+1].x for all s */
 };
 
 struct WalkParams {
@@ -160,32 +163,36 @@ DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   return c;
 }
 
-/* Candidate scan of one contiguous slice of reference records: 4 records (128
- * bytes) are requested before the first is examined, so that the L2 round trips
- * of a slice overlap instead of queueing behind each other. */
+/* Candidate scan of one micro-cell: 4 records (128 bytes) are requested before the
+ * first is examined, so that the L2 round trips overlap instead of queueing.
+ * Ties: the reference keeps the FIRST candidate with the smallest d (strict <,
+ * simulations.py:981); cells are visited out of list order, so within one
+ * subvoxel an equal d wins only if its position in the reference's list is
+ * lower than the current holder's (pass_pos = INT_MIN once a later subvoxel
+ * starts: candidates of an earlier subvoxel always keep a tie). */
 DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step,
-                         double &min_d, int &closest) {
+                         double &min_d, int &closest, int &pass_pos) {
   for (int i = begin; i < end; i += 4) {
     float4 b0[4], b1[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int j = min(i + u, end - 1);
-      b0[u] = ms.ref_box[2 * j];
-      b1[u] = ms.ref_box[2 * j + 1];
+      b0[u] = ms.mrec[2 * j];
+      b1[u] = ms.mrec[2 * j + 1];
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (i + u >= end) break;
-      /* 32-byte reference record: float32 AABB of the triangle + its index */
       if (b0[u].x > cb.hix || b0[u].w < cb.lox || b0[u].y > cb.hiy || b1[u].x < cb.loy || b0[u].z > cb.hiz ||
           b1[u].y < cb.loz)
         continue;
-      int ti = __float_as_int(b1[u].z);
+      int ti = __float_as_int(b1[u].z), pos = __float_as_int(b1[u].w);
       const double *rec = ms.tri + (int64_t)ti * 9;
       double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
-      if (d > 0 && d < min_d) {
+      if (d > 0 && (d < min_d || (d == min_d && pos < pass_pos))) {
         closest = ti;
         min_d = d;
+        pass_pos = pos;
       }
     }
   }
@@ -228,12 +235,7 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
           y -= sn * ny;
           shy = (double)sn * Ly;
         }
-        /* z is the fastest index of the CSR index, so the reference lists of a run of
-         * consecutive z subvoxels inside one periodic image are ONE contiguous slice
-         * of references: two range loads per (x, y) column instead of one per subvoxel.
-         * The candidates are visited in the same order as subvoxel by subvoxel. */
-        int zi = llz;
-        while (zi < ulz) {
+        for (int zi = llz; zi < ulz; zi++) {
           int z = zi;
           double shz = 0;
           if (z < 0 || z > nz - 1) {
@@ -241,14 +243,28 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
             z -= sn * nz;
             shz = (double)sn * Lz;
           }
-          int run = ms.csr_contiguous ? min(ulz - zi, nz - z) : 1;
-          zi += run;
-          int sv = (x * ny + y) * nz + z;
-          int begin = ms.sv_range[sv].x, end = ms.sv_range[sv + run - 1].y;
-          if (begin >= end) continue;
+          const int sv = (x * ny + y) * nz + z;
+          const int2 mg = ms.sv_micro[sv];
+          if (mg.x == 0) continue; /* empty subvoxel */
           V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
           const CullBox cb = make_cull_box(tr0, step, step_l);
-          scan_candidates(ms, begin, end, cb, tr0, step, min_d, closest);
+          int pass_pos = INT_MIN;
+          if (mg.y == 0) {
+            const int2 cr = ms.cell_range[mg.x];
+            scan_candidates(ms, cr.x, cr.y, cb, tr0, step, min_d, closest, pass_pos);
+          } else {
+            const int k = 1 << mg.y;
+            const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
+            const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
+            const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
+            const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+            for (int a = a0; a <= a1; a++)
+              for (int b = b0; b <= b1; b++)
+                for (int c = c0; c <= c1; c++) {
+                  const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
+                  scan_candidates(ms, cr.x, cr.y, cb, tr0, step, min_d, closest, pass_pos);
+                }
+          }
         }
       }
     }
