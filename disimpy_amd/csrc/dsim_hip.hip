@@ -5,6 +5,7 @@
  * gfx950 only, with -ffp-contract=off (see dsim_device.h).
  */
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -220,6 +221,16 @@ struct dsim_sim {
   double last_ms = 0;
   int last_launches = 0;
   int block_size = 256, tile_steps = 0, meas_per_pass = 0;
+  int resort_steps = 0; /* mesh: 0 = automatic, < 0 = never re-sort the walkers */
+  /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
+  bool sort_ready = false;
+  double *phase_alt = nullptr;
+  uint8_t *exc_alt = nullptr;
+  int32_t *orig[2] = {nullptr, nullptr}, *perm = nullptr, *iota = nullptr;
+  uint32_t *keys[2] = {nullptr, nullptr};
+  int orig_cur = 0;
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
 };
 
 static void free_mesh(DevMesh &m) {
@@ -260,6 +271,15 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->nexc_partial) (void)hipFree(h->nexc_partial);
   if (h->sig_out) (void)hipFree(h->sig_out);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->phase_alt) (void)hipFree(h->phase_alt);
+  if (h->exc_alt) (void)hipFree(h->exc_alt);
+  for (int b = 0; b < 2; b++) {
+    if (h->orig[b]) (void)hipFree(h->orig[b]);
+    if (h->keys[b]) (void)hipFree(h->keys[b]);
+  }
+  if (h->perm) (void)hipFree(h->perm);
+  if (h->iota) (void)hipFree(h->iota);
+  if (h->sort_tmp) (void)hipFree(h->sort_tmp);
   free_mesh(h->mesh);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -339,7 +359,7 @@ extern "C" int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int6
   return DSIM_OK;
 }
 
-extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass) {
+extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass, int32_t resort_steps) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (block_size) {
     if (block_size < 64 || block_size > 256 || block_size % 64) return fail(DSIM_ERR_INVALID, "block_size must be 64, 128, 192 or 256");
@@ -347,6 +367,7 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
   }
   if (tile_steps > 0) h->tile_steps = tile_steps;
   if (meas_per_pass > 0) h->meas_per_pass = meas_per_pass;
+  if (resort_steps != 0) h->resort_steps = resort_steps;
   return DSIM_OK;
 }
 
@@ -652,6 +673,77 @@ static int pick_mb(int M, int forced) {
   return mb;
 }
 
+/* ---- spatial re-sorting of walkers (mesh substrates) ------------------------------
+ * Walkers are independent, so their slots may be permuted freely.  Every
+ * `resort` time steps the walkers are sorted by the Morton code of their
+ * (periodically wrapped) position, so that the lanes of a wavefront sit in the
+ * same few subvoxels: their index / triangle gathers then hit the same cache
+ * lines (the vector L1 serves a wave-wide load at one line per cycle, so 64
+ * scattered addresses cost ~64x a coherent one) and their candidate loops have
+ * similar trip counts.  At the end of the run the original walker order is
+ * restored, so no other entry point sees the permutation. */
+
+static int ensure_sort_buffers(dsim_sim *h) {
+  if (h->sort_ready) return DSIM_OK;
+  const int64_t n = h->n;
+  HIP_TRY(hipMalloc(&h->phase_alt, (size_t)h->M * n * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->exc_alt, n));
+  for (int b = 0; b < 2; b++) {
+    HIP_TRY(hipMalloc(&h->orig[b], n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->keys[b], n * sizeof(uint32_t)));
+  }
+  HIP_TRY(hipMalloc(&h->perm, n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->iota, n * sizeof(int32_t)));
+  iota_kernel<<<grid_for(n, 256), 256, 0, h->stream>>>(h->iota, n);
+  HIP_TRY(hipGetLastError());
+  size_t bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 30, h->stream));
+  HIP_TRY(hipMalloc(&h->sort_tmp, bytes));
+  h->sort_tmp_bytes = bytes;
+  h->sort_ready = true;
+  return DSIM_OK;
+}
+
+/* sort the walkers of the current state buffer by Morton key; flips h->cur */
+static int resort_walkers(dsim_sim *h, bool first) {
+  const int64_t n = h->n;
+  const int g = grid_for(n, 256);
+  const int c = h->cur, o = 1 - h->cur;
+  const DevMesh &dm = h->mesh;
+  morton_key_kernel<<<g, 256, 0, h->stream>>>(h->x[c], h->y[c], h->z[c], n, dm.inv_l[0], dm.inv_l[1], dm.inv_l[2], h->keys[0]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 30, h->stream));
+  gather_state_kernel<<<g, 256, 0, h->stream>>>(h->perm, n, h->x[c], h->y[c], h->z[c], h->s0[c], h->s1[c], h->exc, first ? h->iota : h->orig[h->orig_cur],
+                                                h->x[o], h->y[o], h->z[o], h->s0[o], h->s1[o], h->exc_alt, h->orig[1 - h->orig_cur]);
+  HIP_TRY(hipGetLastError());
+  dim3 pg(g, h->M);
+  gather_rows_kernel<<<pg, 256, 0, h->stream>>>(h->perm, n, h->phase, h->phase_alt);
+  HIP_TRY(hipGetLastError());
+  std::swap(h->phase, h->phase_alt);
+  std::swap(h->exc, h->exc_alt);
+  h->orig_cur = 1 - h->orig_cur;
+  h->cur = o;
+  return DSIM_OK;
+}
+
+/* undo the permutation: slot i goes back to walker orig[i]; flips h->cur */
+static int restore_walker_order(dsim_sim *h) {
+  const int64_t n = h->n;
+  const int g = grid_for(n, 256);
+  const int c = h->cur, o = 1 - h->cur;
+  const int32_t *orig = h->orig[h->orig_cur];
+  scatter_state_kernel<<<g, 256, 0, h->stream>>>(orig, n, h->x[c], h->y[c], h->z[c], h->s0[c], h->s1[c], h->exc, h->x[o], h->y[o], h->z[o],
+                                                 h->s0[o], h->s1[o], h->exc_alt);
+  HIP_TRY(hipGetLastError());
+  dim3 pg(g, h->M);
+  scatter_rows_kernel<<<pg, 256, 0, h->stream>>>(orig, n, h->phase, h->phase_alt);
+  HIP_TRY(hipGetLastError());
+  std::swap(h->phase, h->phase_alt);
+  std::swap(h->exc, h->exc_alt);
+  h->cur = o;
+  return DSIM_OK;
+}
+
 static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_t t_end) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (t_begin < 0 || t_end > h->T || t_begin > t_end) return fail(DSIM_ERR_INVALID, "time range [%d, %d) outside [0, %d)", t_begin, t_end, h->T);
@@ -661,24 +753,9 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   if (t_begin == t_end) return DSIM_OK;
   const int mb = pick_mb(h->M, h->meas_per_pass);
   const int passes = (h->M + mb - 1) / mb;
-  const int src = h->cur, dst = passes > 1 ? 1 - h->cur : h->cur;
   p.n = h->n;
-  p.x_in = h->x[src];
-  p.y_in = h->y[src];
-  p.z_in = h->z[src];
-  p.s0_in = h->s0[src];
-  p.s1_in = h->s1[src];
-  p.x_out = h->x[dst];
-  p.y_out = h->y[dst];
-  p.z_out = h->z[dst];
-  p.s0_out = h->s0[dst];
-  p.s1_out = h->s1[dst];
-  p.phase = h->phase;
-  p.exc = h->exc;
   p.g4 = h->g4;
   p.M = h->M;
-  p.t_begin = t_begin;
-  p.t_end = t_end;
   p.step_l = h->step_l;
   p.gdt = DSIM_GAMMA * h->dt;
   /* LDS budget: 1 KB log table + subvoxel boundaries + <= 16 KB of gradient tile */
@@ -691,28 +768,71 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   if (lds > 64 * 1024) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int block = h->block_size;
   const int grid = grid_for(h->n, block);
-  HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  for (int pass = 0; pass < passes; pass++) {
-    p.m0 = pass * mb;
-    p.mc = std::min(mb, h->M - p.m0);
-    p.write_state = pass == passes - 1;
-    hipError_t e;
-    switch (geom) {
-      case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream); break;
-      case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream); break;
-      case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream); break;
-      case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream); break;
-      default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream); break;
+  /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
+  int resort = 0;
+  if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX) {
+    resort = h->resort_steps;
+    if (resort == 0) {
+      double hmin = 1e300;
+      for (int k = 0; k < 3; k++)
+        if (h->mesh.inv_h[k] > 0) hmin = std::min(hmin, 1.0 / h->mesh.inv_h[k]);
+      double r = h->step_l > 0 ? hmin / h->step_l : 1e3;
+      resort = (int)std::min(1024.0, std::max(32.0, 0.75 * r * r));
     }
-    if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    h->last_launches++;
+    int rc = ensure_sort_buffers(h);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  bool permuted = false;
+  for (int ta = t_begin; ta < t_end;) {
+    const int tb = resort > 0 ? std::min(t_end, ta + resort) : t_end;
+    if (resort > 0) {
+      int rc = resort_walkers(h, !permuted);
+      if (rc) return rc;
+      permuted = true;
+    }
+    const int src = h->cur, dst = passes > 1 ? 1 - h->cur : h->cur;
+    p.x_in = h->x[src];
+    p.y_in = h->y[src];
+    p.z_in = h->z[src];
+    p.s0_in = h->s0[src];
+    p.s1_in = h->s1[src];
+    p.x_out = h->x[dst];
+    p.y_out = h->y[dst];
+    p.z_out = h->z[dst];
+    p.s0_out = h->s0[dst];
+    p.s1_out = h->s1[dst];
+    p.phase = h->phase;
+    p.exc = h->exc;
+    p.t_begin = ta;
+    p.t_end = tb;
+    for (int pass = 0; pass < passes; pass++) {
+      p.m0 = pass * mb;
+      p.mc = std::min(mb, h->M - p.m0);
+      p.write_state = pass == passes - 1;
+      hipError_t e;
+      switch (geom) {
+        case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream); break;
+        case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream); break;
+        case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream); break;
+        case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream); break;
+        default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream); break;
+      }
+      if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+      h->last_launches++;
+    }
+    h->cur = dst;
+    ta = tb;
+  }
+  if (permuted) {
+    int rc = restore_walker_order(h);
+    if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  h->cur = dst;
   return DSIM_OK;
 }
 

@@ -499,6 +499,80 @@ __global__ void soa_to_states_kernel(const uint64_t *s0, const uint64_t *s1, int
   }
 }
 
+/* ---- spatial re-sorting of walker slots (mesh substrates) -------------------------- */
+
+DSD uint32_t spread10(uint32_t v) { /* 10 bits -> every third bit */
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+/* 30-bit Morton code of the position wrapped into the periodic voxel (1024^3 cells).
+ * Only a sort key: approximate arithmetic is fine, results never depend on it. */
+__global__ void morton_key_kernel(const double *x, const double *y, const double *z, int64_t n, double inv_lx, double inv_ly,
+                                  double inv_lz, uint32_t *keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double fx = x[i] * inv_lx, fy = y[i] * inv_ly, fz = z[i] * inv_lz;
+  fx -= __builtin_floor(fx);
+  fy -= __builtin_floor(fy);
+  fz -= __builtin_floor(fz);
+  uint32_t ix = fx == fx ? (uint32_t)min(1023, max(0, (int)(fx * 1024.0))) : 0u;
+  uint32_t iy = fy == fy ? (uint32_t)min(1023, max(0, (int)(fy * 1024.0))) : 0u;
+  uint32_t iz = fz == fz ? (uint32_t)min(1023, max(0, (int)(fz * 1024.0))) : 0u;
+  keys[i] = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
+}
+
+__global__ void iota_kernel(int32_t *v, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (int32_t)i;
+}
+
+/* slot i of the new order takes the walker that sat in slot perm[i] */
+__global__ void gather_state_kernel(const int32_t *perm, int64_t n, const double *x, const double *y, const double *z,
+                                    const uint64_t *s0, const uint64_t *s1, const uint8_t *exc, const int32_t *orig,
+                                    double *xo, double *yo, double *zo, uint64_t *s0o, uint64_t *s1o, uint8_t *exco,
+                                    int32_t *origo) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t j = perm[i];
+  xo[i] = x[j];
+  yo[i] = y[j];
+  zo[i] = z[j];
+  s0o[i] = s0[j];
+  s1o[i] = s1[j];
+  exco[i] = exc[j];
+  origo[i] = orig[j];
+}
+
+__global__ void gather_rows_kernel(const int32_t *perm, int64_t n, const double *src, double *dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(int64_t)blockIdx.y * n + i] = src[(int64_t)blockIdx.y * n + perm[i]];
+}
+
+/* slot i returns to walker index orig[i] */
+__global__ void scatter_state_kernel(const int32_t *orig, int64_t n, const double *x, const double *y, const double *z,
+                                     const uint64_t *s0, const uint64_t *s1, const uint8_t *exc, double *xo, double *yo,
+                                     double *zo, uint64_t *s0o, uint64_t *s1o, uint8_t *exco) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t j = orig[i];
+  xo[j] = x[i];
+  yo[j] = y[i];
+  zo[j] = z[i];
+  s0o[j] = s0[i];
+  s1o[j] = s1[i];
+  exco[j] = exc[i];
+}
+
+__global__ void scatter_rows_kernel(const int32_t *orig, int64_t n, const double *src, double *dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(int64_t)blockIdx.y * n + orig[i]] = src[(int64_t)blockIdx.y * n + i];
+}
+
 /* ---- _cuda_fill_mesh (simulations.py:421-502) ------------------------------------ */
 
 struct FillParams {

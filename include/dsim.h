@@ -146,8 +146,11 @@ int dsim_interval_sv_overlap(const double *xs, int64_t n_xs, double x1, double x
 int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
 
 /* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
- * LDS gradient tile, measurements held in registers per pass. */
-int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass);
+ * LDS gradient tile, measurements held in registers per pass, and - for mesh
+ * substrates - the number of time steps between spatial re-sorts of the walker
+ * slots (0 = automatic, negative = never; results do not depend on it). */
+int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass,
+                    int32_t resort_steps);
 
 #ifdef __cplusplus
 }

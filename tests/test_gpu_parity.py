@@ -303,6 +303,27 @@ def test_mesh_bit_identical(lib, oracle_exact, periodic, n_sv, perm_prob):
         assert (gpu["pos"] > 0).all() and (gpu["pos"] < sub.voxel_size).all()
 
 
+@pytest.mark.parametrize("resort_steps", [-1, 7, 0])
+def test_mesh_spatial_resorting_is_invisible(lib, oracle_exact, resort_steps):
+    """>= 4096 walkers: the mesh path re-sorts the walker slots by Morton key every few
+    steps (tuning knob) and restores the order at the end; per-walker results must not move."""
+    from disimpy_amd import substrates
+
+    m = golden("cylinder_mesh_closed.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.array([1e-6, 1e-6, 0.0]),
+                          n_sv=np.array([6, 6, 12]), quiet=True)
+    n, T, dt, M = 6000, 40, 5e-4, 3
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(M, T)
+    pos0 = np.random.RandomState(18).random_sample((n, 3)) * sub.voxel_size
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma, tuning=dict(resort_steps=resort_steps),
+                   chunks=[0, 13, 40])
+    _assert_identical(gpu, ref)
+
+
 def test_mesh_neuron_bit_identical_and_contained(lib, oracle_exact):
     """The 29 688-triangle neuron of the reference's tests at the default 50^3 index."""
     from disimpy_amd import simulations, substrates
