@@ -1,0 +1,34 @@
+"""disimpy_amd/csrc/dsim_math.h (the product's bit-reproducible logf / cos) against
+glibc, through the oracle's two builds (exact build = dsim_math.h, default = glibc)."""
+import numpy as np
+
+
+def _ulp_f32(x):
+    return np.spacing(np.abs(x).astype(np.float32)).astype(np.float64)
+
+
+def test_logf_is_correctly_rounded_on_samples(oracle_exact, oracle_libm):
+    rng = np.random.RandomState(0)
+    bits = rng.randint(0x00800000, 0x3F800001, size=200000).astype(np.uint32)
+    xs = np.concatenate([bits.view(np.float32), np.float32([1.0, 0.5, 2.0**-53, 0.99999994, 1.2e-38])])
+    mine = np.array([oracle_exact.lib.dso_u_logf(float(x)) for x in xs], dtype=np.float32)
+    cr = np.log(xs.astype(np.float64)).astype(np.float32)  # float64 log rounded once: correctly rounded except ~1e-8 of inputs
+    assert np.array_equal(mine, cr)
+    gl = np.array([oracle_libm.lib.dso_u_logf(float(x)) for x in xs[:20000]], dtype=np.float32)
+    assert np.abs(mine[:20000].astype(np.float64) - gl) .max() <= _ulp_f32(gl).max()  # glibc logf is within 1 ulp
+    assert oracle_exact.lib.dso_u_logf(0.0) == -np.inf
+    assert oracle_exact.lib.dso_u_logf(1.0) == 0.0
+
+
+def test_cos_0_2pi_within_1p5_ulp(oracle_exact):
+    rng = np.random.RandomState(1)
+    u = rng.randint(0, 2**24, size=100000).astype(np.float64) / 2**24
+    u = np.concatenate([u, [0.0, 0.25, 0.5, 0.75, 1.0 - 2.0**-24, 2.0**-30]])
+    x = 6.283185307179586 * u.astype(np.float32).astype(np.float64)
+    mine = np.array([oracle_exact.lib.dso_u_cos(float(v)) for v in x])
+    ref = np.cos(x.astype(np.longdouble))
+    err = np.abs(mine - ref).astype(np.float64)
+    ulp = np.spacing(np.abs(ref).astype(np.float64))
+    big = np.abs(ref) > 1e-6  # next to the zeros of cos only the ABSOLUTE error is bounded
+    assert (err[big] / ulp[big]).max() < 1.6
+    assert err.max() < 2e-16

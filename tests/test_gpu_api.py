@@ -1,0 +1,265 @@
+"""End-to-end tests through the public API on an MI355X, mirroring the
+reference's own end-to-end tests (disimpy/tests/test_simulations.py:469-832):
+analytic free diffusion, MISST fixtures, containment, ellipsoid == sphere,
+mesh == MISST cylinder + no leaks, neuron containment; plus BASELINE config C2
+at full size (1e6 spins x 1e3 steps x 32 directions)."""
+import os
+import warnings
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+D = 2e-9
+
+
+@pytest.fixture(scope="module")
+def api():
+    from disimpy_amd import _lib, gradients, simulations, substrates
+
+    assert _lib.device_count() > 0, "these tests need an AMD GPU"
+    return gradients, simulations, substrates
+
+
+def example_gradient():
+    T = 80e-3
+    g = np.zeros((1, 100, 3))
+    g[0, 1:11, 0] = 1
+    g[0, -11:-1, 0] = -1
+    return g, T / (g.shape[1] - 1)
+
+
+def misst_gradient(gradients, short, n_t=1000):
+    """Waveforms of test_simulations.py:530-538 (delta = 30 ms) and :551-559 (delta = 1 ms)."""
+    if short:
+        T, g = 41e-3, np.zeros((1, 410, 3))
+        g[0, 1:10, 0] = 1
+        g[0, -10:-1, 0] = -1
+    else:
+        T, g = 70e-3, np.zeros((1, 700, 3))
+        g[0, 1:300, 0] = 1
+        g[0, -300:-1, 0] = -1
+    bs = np.linspace(1, 3e9, 100)
+    g = np.concatenate([g for _ in bs], axis=0)
+    dt = T / (g.shape[1] - 1)
+    g, dt = gradients.interpolate_gradient(g, dt, n_t)
+    return gradients.set_b(g, dt, bs), dt
+
+
+def test_free_diffusion_signal_and_trajectories(api, tmp_path):
+    """test_simulations.py:469-500."""
+    gradients, simulations, substrates = api
+    n_s, n_t = int(1e5), int(1e3)
+    g, dt = example_gradient()
+    bs = np.linspace(1, 2e9, 100)
+    g = np.concatenate([g for _ in bs], axis=0)
+    g, dt = gradients.interpolate_gradient(g, dt, n_t)
+    g = gradients.set_b(g, dt, bs)
+    signals = simulations.simulation(n_s, D, g, dt, substrates.free(), quiet=True)
+    assert signals.shape == (100,)
+    npt.assert_almost_equal(signals / n_s, np.exp(-bs * D), 2)
+    # trajectories file
+    n_s, n_t = int(1e3), int(1e2)
+    g, dt = example_gradient()
+    g, dt = gradients.interpolate_gradient(g, dt, n_t)
+    traj_file = str(tmp_path / "example_traj.txt")
+    simulations.simulation(n_s, D, g, dt, substrates.free(), traj=traj_file, quiet=True)
+    traj = np.loadtxt(traj_file)
+    assert traj.shape == (n_t + 1, n_s * 3)
+    traj = traj.reshape((n_t + 1, n_s, 3))
+    assert np.all(traj[0] == 0)
+    npt.assert_almost_equal(np.mean(traj[-1], axis=0), 0, 5)
+    npt.assert_allclose(np.linalg.norm(np.diff(traj, axis=0), axis=2), np.sqrt(6 * D * dt), rtol=1e-9)
+
+
+def test_api_output_shapes_and_progress_printing(api, capsys):
+    gradients, simulations, substrates = api
+    g, dt = example_gradient()
+    g = np.concatenate([g, 2 * g], axis=0)
+    out = simulations.simulation(200, D, g, dt, substrates.free(), all_signals=True, quiet=True)
+    assert out.shape == (2, 200) and np.all(np.abs(out) <= 1)
+    sig, pos = simulations.simulation(200, D, g, dt, substrates.free(), final_pos=True, quiet=True)
+    assert sig.shape == (2,) and pos.shape == (200, 3)
+    npt.assert_allclose(sig, out.sum(axis=1), atol=1e-9)
+    simulations.simulation(200, D, g, dt, substrates.free())
+    printed = capsys.readouterr().out
+    for needle in ("Starting simulation", "Number of random walkers = 200", "Number of steps = 100", "Step length = ",
+                   "Simulation finished"):
+        assert needle in printed
+    # the same seed gives the same result; another seed does not
+    a = simulations.simulation(200, D, g, dt, substrates.free(), quiet=True, seed=5)
+    b = simulations.simulation(200, D, g, dt, substrates.free(), quiet=True, seed=5)
+    c = simulations.simulation(200, D, g, dt, substrates.free(), quiet=True, seed=6)
+    npt.assert_array_equal(a, b)
+    assert np.all(a != c)
+
+
+def test_c2_full_size_analytic(api):
+    """BASELINE config C2: 1e6 spins x 1e3 steps x 32 PGSE directions, b*D = 2.
+    sigma(S/N) ~ sqrt((1 - exp(-4)) / 2 / N) = 7e-4: every direction within 5 sigma of exp(-2)."""
+    gradients, simulations, substrates = api
+    k = np.arange(32)
+    z = 1 - (2 * k + 1) / 32
+    phi = k * np.pi * (3 - np.sqrt(5))
+    dirs = np.stack([np.sqrt(1 - z**2) * np.cos(phi), np.sqrt(1 - z**2) * np.sin(phi), z], axis=1)
+    g, dt = gradients.pgse(10e-3, 40e-3, 1000, 1e9 * np.ones(32), dirs)
+    n = int(1e6)
+    s = simulations.simulation(n, D, g, dt, substrates.free(), quiet=True)
+    assert np.abs(s / n - np.exp(-2.0)).max() < 5 * 7e-4
+    assert abs(np.mean(s / n) - np.exp(-2.0)) < 5e-4
+
+
+def test_cylinder_diffusion(api, tmp_path):
+    """test_simulations.py:503-589."""
+    gradients, simulations, substrates = api
+    n_s, n_t = int(1e2), int(1e2)
+    g, dt = example_gradient()
+    g, dt = gradients.interpolate_gradient(g, dt, n_t)
+    traj_file = str(tmp_path / "example_traj.txt")
+    for radius in [1e-6, 5e-6, 1e-3]:
+        sub = substrates.cylinder(radius=radius, orientation=np.array([1.0, 0, 0]))
+        simulations.simulation(n_s, D, g, dt, sub, traj=traj_file, quiet=True)
+        traj = np.loadtxt(traj_file).reshape((n_t + 1, n_s, 3))
+        max_pos = np.max(np.linalg.norm(traj[..., 1::], axis=2))
+        assert max_pos < radius
+        npt.assert_almost_equal(max_pos, radius)
+    misst = golden("misst_signals.npz")
+    n_s = int(1e5)
+    sub = substrates.cylinder(orientation=np.array([0, 0, 1.0]), radius=5e-6)
+    for short, key in ((False, "cylinder_30ms"), (True, "cylinder_1ms")):
+        g, dt = misst_gradient(gradients, short)
+        s = simulations.simulation(n_s, D, g, dt, sub, quiet=True)
+        npt.assert_almost_equal(s / n_s, misst[key], 2)
+    # rotation invariance and the axis-parallel case
+    g, dt = example_gradient()
+    bs = np.linspace(1, 3e9, 100)
+    g = np.concatenate([g for _ in bs], axis=0)
+    g, dt = gradients.interpolate_gradient(g, dt, int(1e3))
+    g = gradients.set_b(g, dt, bs)
+    s1 = simulations.simulation(n_s, D, g, dt, substrates.cylinder(orientation=np.array([1.0, 0, 1.0]), radius=5e-6),
+                                quiet=True)
+    s2 = simulations.simulation(n_s, D, g, dt, substrates.cylinder(orientation=-np.array([1.0, 0, 1.0]), radius=5e-6),
+                                quiet=True)
+    npt.assert_almost_equal(s1 / n_s, s2 / n_s)
+    s3 = simulations.simulation(n_s, D, g, dt, substrates.cylinder(orientation=-np.array([1.0, 0, 0]), radius=5e-6),
+                                quiet=True)
+    npt.assert_almost_equal(s3 / n_s, np.exp(-bs * D), 2)
+
+
+def test_sphere_diffusion(api, tmp_path):
+    """test_simulations.py:592-654."""
+    gradients, simulations, substrates = api
+    n_s, n_t = int(1e2), int(1e2)
+    g, dt = example_gradient()
+    g, dt = gradients.interpolate_gradient(g, dt, n_t)
+    traj_file = str(tmp_path / "example_traj.txt")
+    radius = 5e-6
+    simulations.simulation(n_s, D, g, dt, substrates.sphere(radius), traj=traj_file, quiet=True)
+    traj = np.loadtxt(traj_file).reshape((n_t + 1, n_s, 3))
+    max_pos = np.max(np.linalg.norm(traj, axis=2))
+    assert max_pos < radius
+    npt.assert_almost_equal(max_pos, radius)
+    misst = golden("misst_signals.npz")
+    n_s = int(1e5)
+    for short, key in ((False, "sphere_30ms"), (True, "sphere_1ms")):
+        g, dt = misst_gradient(gradients, short)
+        s = simulations.simulation(n_s, D, g, dt, substrates.sphere(radius=5e-6), quiet=True)
+        npt.assert_almost_equal(s / n_s, misst[key], 2)
+
+
+def test_ellipsoid_equals_sphere(api, tmp_path):
+    """test_simulations.py:657-683: with equal semiaxes the two kernels give the same signal to 7 decimals."""
+    gradients, simulations, substrates = api
+    n_s, n_t = int(1e2), int(1e2)
+    g, dt = example_gradient()
+    g, dt = gradients.interpolate_gradient(g, dt, n_t)
+    traj_file = str(tmp_path / "example_traj.txt")
+    radius = 5e-6
+    s_e = simulations.simulation(n_s, D, g, dt, substrates.ellipsoid(np.ones(3) * radius), traj=traj_file, quiet=True)
+    traj = np.loadtxt(traj_file).reshape((n_t + 1, n_s, 3))
+    max_pos = np.max(np.linalg.norm(traj, axis=2))
+    assert max_pos < radius
+    npt.assert_almost_equal(max_pos, radius)
+    s_s = simulations.simulation(n_s, D, g, dt, substrates.sphere(radius), quiet=True)
+    npt.assert_almost_equal(s_e, s_s)
+
+
+def test_iteration_limit_warning(api):
+    gradients, simulations, substrates = api
+    g, dt = example_gradient()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s = simulations.simulation(50, D, g, 1.0, substrates.sphere(1e-7), quiet=True, max_iter=2)
+    assert any("Maximum number of iterations was exceeded" in str(x.message) for x in w)
+    assert np.all(np.isfinite(s))
+    out = simulations.simulation(50, D, g, 1.0, substrates.sphere(1e-7), quiet=True, max_iter=2, all_signals=True)
+    assert np.isnan(out).any()
+
+
+def test_mesh_diffusion_closed_cylinder(api):
+    """test_simulations.py:686-762 (a subset of its 12 parameter combinations to bound the run time)."""
+    gradients, simulations, substrates = api
+    m = golden("cylinder_mesh_closed.npz")
+    misst = golden("misst_signals.npz")["cylinder_30ms"]
+    n_s = int(1e4)
+    g, dt = misst_gradient(gradients, False)
+    for periodic, pad, n_sv in [(True, 0.0, [1, 1, 1]), (True, 1e-6, [10, 10, 10]), (False, 0.0, [1, 5, 20]),
+                                (False, 1e-6, [10, 10, 10])]:
+        padding = np.zeros(3) + pad
+        sub = substrates.mesh(m["vertices"], m["faces"], periodic, padding=padding, init_pos="intra",
+                              n_sv=np.array(n_sv), quiet=True)
+        s, pos = simulations.simulation(n_s, D, g, dt, sub, final_pos=True, quiet=True)
+        npt.assert_almost_equal(s / n_s, misst, 2)
+        r = np.max(np.linalg.norm(sub.vertices[:, 0:2] - (sub.voxel_size[0:2] - padding[0:2] * 2) / 2, axis=1))
+        assert np.min(pos[:, 2]) > 0 and np.max(pos[:, 2]) < sub.voxel_size[2]
+        assert np.max(np.linalg.norm(pos[:, 0:2] - np.max(sub.vertices, axis=0)[0:2] / 2, axis=1)) < r
+
+
+def test_mesh_diffusion_open_periodic_cylinder(api):
+    """test_simulations.py:764-812: walkers leave the voxel along z but never the cylinder."""
+    gradients, simulations, substrates = api
+    m = golden("cylinder_mesh_open.npz")
+    n_s = int(1e4)
+    g, dt = misst_gradient(gradients, False)
+    init_pos = np.zeros((n_s, 3)) + np.array([5e-6, 5e-6, 12.5e-6])
+    for padding in [np.zeros(3), np.array([1e-6, 1e-6, 0])]:
+        for n_sv in [np.array([1, 1, 1]), np.array([1, 5, 20]), np.array([10, 10, 10])]:
+            sub = substrates.mesh(m["vertices"], m["faces"], init_pos=init_pos + padding, periodic=True,
+                                  padding=padding, n_sv=n_sv, quiet=True)
+            s, pos = simulations.simulation(n_s, D, g, dt, sub, final_pos=True, quiet=True)
+            r = np.max(np.linalg.norm(sub.vertices[:, 0:2] - (sub.voxel_size[0:2] - padding[0:2] * 2) / 2, axis=1))
+            assert np.min(pos[:, 2]) < 0 and np.max(pos[:, 2]) > sub.voxel_size[2]
+            assert np.max(np.linalg.norm(pos[:, 0:2] - np.max(sub.vertices, axis=0)[0:2] / 2, axis=1)) < r
+
+
+def test_mesh_diffusion_neuron_no_leak(api):
+    """test_simulations.py:814-831."""
+    gradients, simulations, substrates = api
+    m = golden("neuron_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), init_pos="intra", periodic=True, quiet=True)
+    g = np.ones((1, 100, 3))
+    for dt in [1e-5, 1e-3, 1e-1]:
+        s, pos = simulations.simulation(int(1e3), D, g, dt, sub, final_pos=True, quiet=True)
+        assert np.all(np.max(pos, axis=0) < sub.voxel_size) and np.all(np.min(pos, axis=0) > 0)
+
+
+def test_fill_mesh_statistics(api):
+    """test_simulations.py:428-457."""
+    gradients, simulations, substrates = api
+    m = golden("sphere_mesh.npz")
+    n_s = int(1e4)
+    for n_sv in [np.array([1, 1, 1]), np.array([1, 5, 20]), np.array([10, 10, 10])]:
+        for periodic in [True, False]:
+            for padding in [np.zeros(3), np.zeros(3) + 1e-6]:
+                sub = substrates.mesh(m["vertices"], m["faces"], periodic, padding=padding, n_sv=n_sv, quiet=True)
+                r = (sub.voxel_size - padding * 2) / 2
+                pts = simulations._fill_mesh(n_s, sub, True, seed=123) - (r + padding)
+                assert np.max(np.linalg.norm(pts, axis=1)) < r.max()
+                npt.assert_almost_equal(np.mean(pts, axis=0), np.zeros(3))
+                pts = simulations._fill_mesh(n_s, sub, False, seed=123) - (r + padding)
+                assert np.min(np.linalg.norm(pts, axis=1)) > 0.9 * r.min()
+                npt.assert_almost_equal(np.mean(pts, axis=0), np.zeros(3))
