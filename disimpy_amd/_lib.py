@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdsim_hip.so")
+LIB_PATH = os.environ.get("DSIM_LIB") or os.path.join(_HERE, "csrc", "libdsim_hip.so")
 
 # every symbol include/dsim.h declares (checked by tests/test_abi.py)
 SYMBOLS = (

@@ -836,6 +836,16 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   return DSIM_OK;
 }
 
+#ifdef DSIM_STATS
+/* development build only: read and clear the traversal counters */
+extern "C" int dsim_debug_stats(unsigned long long *out32) {
+  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(dsim_stats), 32 * sizeof(unsigned long long)));
+  unsigned long long zero[32] = {0};
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dsim_stats), zero, sizeof(zero)));
+  return DSIM_OK;
+}
+#endif
+
 extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_ms;

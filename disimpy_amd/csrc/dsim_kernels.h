@@ -18,6 +18,20 @@
 
 #include "dsim_device.h"
 
+/* Development build (-DDSIM_STATS): event counters for the mesh traversal.  STAT_LANE
+ * counts once per lane, STAT_WAVE once per wavefront that reaches the point. */
+#ifdef DSIM_STATS
+__device__ unsigned long long dsim_stats[32];
+#define STAT_LANE(i) atomicAdd(&dsim_stats[i], 1ULL)
+#define STAT_WAVE(i)                                                                         \
+  do {                                                                                       \
+    if ((int)(__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&dsim_stats[16 + (i)], 1ULL); \
+  } while (0)
+#else
+#define STAT_LANE(i)
+#define STAT_WAVE(i)
+#endif
+
 enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };
 
 struct MeshDev {
@@ -173,6 +187,8 @@ DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
 DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step,
                          double &min_d, int &closest, int &pass_pos) {
   for (int i = begin; i < end; i += 4) {
+    STAT_LANE(4);
+    STAT_WAVE(4);
     float4 b0[4], b1[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -183,9 +199,12 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (i + u >= end) break;
+      STAT_LANE(5);
       if (b0[u].x > cb.hix || b0[u].w < cb.lox || b0[u].y > cb.hiy || b1[u].x < cb.loy || b0[u].z > cb.hiz ||
           b1[u].y < cb.loz)
         continue;
+      STAT_LANE(6);
+      STAT_WAVE(6);
       int ti = __float_as_int(b1[u].z), pos = __float_as_int(b1[u].w);
       const double *rec = ms.tri + (int64_t)ti * 9;
       double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
@@ -209,6 +228,8 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
   int closest = 0;
   while (check && step_l > 0 && iter_idx < p.max_iter) {
     iter_idx++;
+    STAT_LANE(0);
+    STAT_WAVE(0);
     double min_d = DS_INF;
     double ex = __builtin_fma(step.x, step_l, r0.x);
     double ey = __builtin_fma(step.y, step_l, r0.y);
@@ -244,12 +265,18 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
             shz = (double)sn * Lz;
           }
           const int sv = (x * ny + y) * nz + z;
+          STAT_LANE(1);
+          STAT_WAVE(1);
           const int2 mg = ms.sv_micro[sv];
           if (mg.x == 0) continue; /* empty subvoxel */
+          STAT_LANE(2);
+          STAT_WAVE(2);
           V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
           const CullBox cb = make_cull_box(tr0, step, step_l);
           int pass_pos = INT_MIN;
           if (mg.y == 0) {
+            STAT_LANE(3);
+            STAT_WAVE(3);
             const int2 cr = ms.cell_range[mg.x];
             scan_candidates(ms, cr.x, cr.y, cb, tr0, step, min_d, closest, pass_pos);
           } else {
@@ -261,6 +288,8 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
             for (int a = a0; a <= a1; a++)
               for (int b = b0; b <= b1; b++)
                 for (int c = c0; c <= c1; c++) {
+                  STAT_LANE(3);
+                  STAT_WAVE(3);
                   const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
                   scan_candidates(ms, cr.x, cr.y, cb, tr0, step, min_d, closest, pass_pos);
                 }
@@ -271,6 +300,8 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
     if (min_d > step_l) {
       check = false;
     } else {
+      STAT_LANE(7);
+      STAT_WAVE(7);
       bool reflect = p.perm_prob < rng_uniform_f64(rng);
       const double *rec = ms.tri + (int64_t)closest * 9;
       V3 n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
