@@ -570,20 +570,33 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       sv_micro[s] = make_int2((int)cell_range.size(), lk);
       for (auto &cl : cells) {
-        int start = (int)(mrec.size() / 2);
+        int start = (int)(mrec.size() / 3);
         for (int32_t i : cl) {
           const float *lo = &lo3[(size_t)(i - begin) * 3], *hi = &hi3[(size_t)(i - begin) * 3];
           float idx_bits, pos_bits;
           int32_t ti = refs[i];
           memcpy(&idx_bits, &ti, sizeof(float));
           memcpy(&pos_bits, &i, sizeof(float));
+          /* supporting plane n.x = c in float32 (unit normal; c from the ROUNDED normal so that the
+           * float32 plane is self-consistent); a degenerate triangle gets n = 0, c = 0 and is never culled */
+          const double *r = &rec[(size_t)ti * 9];
+          double nx = r[4] * r[8] - r[5] * r[7], ny = r[5] * r[6] - r[3] * r[8], nz = r[3] * r[7] - r[4] * r[6];
+          double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+          float fx = 0.f, fy = 0.f, fz = 0.f, fc = 0.f;
+          if (nn > 0 && std::isfinite(nn)) {
+            fx = (float)(nx / nn);
+            fy = (float)(ny / nn);
+            fz = (float)(nz / nn);
+            fc = (float)((double)fx * r[0] + (double)fy * r[1] + (double)fz * r[2]);
+          }
           mrec.push_back(make_float4(lo[0], lo[1], lo[2], hi[0]));
-          mrec.push_back(make_float4(hi[1], hi[2], idx_bits, pos_bits));
+          mrec.push_back(make_float4(hi[1], hi[2], fx, fy));
+          mrec.push_back(make_float4(fz, fc, idx_bits, pos_bits));
         }
-        cell_range.push_back(make_int2(start, (int)(mrec.size() / 2)));
+        cell_range.push_back(make_int2(start, (int)(mrec.size() / 3)));
       }
     }
-    if (mrec.empty()) mrec.resize(2, make_float4(0, 0, 0, 0));
+    if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
   }
   std::vector<double> bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);

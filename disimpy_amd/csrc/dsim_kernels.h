@@ -40,8 +40,9 @@ struct MeshDev {
   const int32_t *tri_idx;  /* [n_refs]                                   */
   const int2 *sv_micro;    /* [prod n_sv]   {first cell, log2 k}: micro-grid of the subvoxel        */
   const int2 *cell_range;  /* [n_cells]     [start, end) into mrec                                  */
-  const float4 *mrec;      /* [n_mrec][2]   {minx miny minz maxx} {maxy maxz tri csr_pos}: float32 AABB
-                              rounded outward + triangle index + position in the reference's list */
+  const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
+                              AABB rounded outward, float32 supporting plane n.x = c, triangle index,
+                              position in the reference's list */
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
@@ -159,6 +160,8 @@ DSD V3 load_v3(const double *p) {
  * the test itself (~1e-16 relative). */
 struct CullBox {
   float lox, loy, loz, hix, hiy, hiz;
+  float ax, ay, az, ex, ey, ez; /* segment end points in float32 */
+  float tau;                    /* plane-side margin */
 };
 
 DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
@@ -174,6 +177,16 @@ DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   c.hix = (float)(__builtin_fmax(a.x, e.x) + mx);
   c.hiy = (float)(__builtin_fmax(a.y, e.y) + my);
   c.hiz = (float)(__builtin_fmax(a.z, e.z) + mz);
+  c.ax = (float)a.x;
+  c.ay = (float)a.y;
+  c.az = (float)a.z;
+  c.ex = (float)e.x;
+  c.ey = (float)e.y;
+  c.ez = (float)e.z;
+  /* float32 evaluation of n.x - c carries an absolute error below ~8 ulp of the largest
+   * coordinate; tau = 16 ulp of it plus the step margin */
+  double big = __builtin_fmax(__builtin_fmax(__builtin_fabs(a.x), __builtin_fabs(a.y)), __builtin_fabs(a.z)) + step_l;
+  c.tau = (float)(ms + 2e-6 * big);
   return c;
 }
 
@@ -189,23 +202,30 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
   for (int i = begin; i < end; i += 4) {
     STAT_LANE(4);
     STAT_WAVE(4);
-    float4 b0[4], b1[4];
+    float4 q0[4], q1[4], q2[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int j = min(i + u, end - 1);
-      b0[u] = ms.mrec[2 * j];
-      b1[u] = ms.mrec[2 * j + 1];
+      q0[u] = ms.mrec[3 * j];
+      q1[u] = ms.mrec[3 * j + 1];
+      q2[u] = ms.mrec[3 * j + 2];
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (i + u >= end) break;
       STAT_LANE(5);
-      if (b0[u].x > cb.hix || b0[u].w < cb.lox || b0[u].y > cb.hiy || b1[u].x < cb.loy || b0[u].z > cb.hiz ||
-          b1[u].y < cb.loz)
+      /* (1) AABB of the triangle vs cull box of the segment */
+      if (q0[u].x > cb.hix || q0[u].w < cb.lox || q0[u].y > cb.hiy || q1[u].x < cb.loy || q0[u].z > cb.hiz ||
+          q1[u].y < cb.loz)
         continue;
+      /* (2) both end points strictly on one side of the triangle's plane (margin tau): the
+       * ray cannot meet the plane at 0 < d <= step_l.  Degenerate triangles have n = 0. */
+      const float s0 = __builtin_fmaf(q2[u].x, cb.az, __builtin_fmaf(q1[u].z, cb.ax, q1[u].w * cb.ay)) - q2[u].y;
+      const float s1 = __builtin_fmaf(q2[u].x, cb.ez, __builtin_fmaf(q1[u].z, cb.ex, q1[u].w * cb.ey)) - q2[u].y;
+      if ((s0 > cb.tau && s1 > cb.tau) || (s0 < -cb.tau && s1 < -cb.tau)) continue;
       STAT_LANE(6);
       STAT_WAVE(6);
-      int ti = __float_as_int(b1[u].z), pos = __float_as_int(b1[u].w);
+      int ti = __float_as_int(q2[u].z), pos = __float_as_int(q2[u].w);
       const double *rec = ms.tri + (int64_t)ti * 9;
       double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
       if (d > 0 && (d < min_d || (d == min_d && pos < pass_pos))) {
