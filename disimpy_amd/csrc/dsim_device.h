@@ -31,13 +31,26 @@ struct Rng {
 
 DSD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
-/* numba/cuda/random.py:79-98 */
+/* numba/cuda/random.py:79-98.  Written on 32-bit halves: gfx950 has no 64-bit
+ * rotate and its 64-bit shifts issue at the fp64 rate, while v_alignbit_b32
+ * (funnel shift) is a full-rate 32-bit op: rotl(x,55) = rotr(x,9) is two of
+ * them, rotl(x,36) is a half swap plus a 4-bit funnel, x<<14 one funnel + one
+ * shift.  Pure integer arithmetic: bit-identical to the 64-bit formulation. */
 DSD uint64_t rng_next(Rng &r) {
-  uint64_t s0 = r.s0, s1 = r.s1;
-  uint64_t result = s0 + s1;
-  s1 ^= s0;
-  r.s0 = rotl64(s0, 55) ^ s1 ^ (s1 << 14);
-  r.s1 = rotl64(s1, 36);
+  uint32_t a0 = (uint32_t)r.s0, a1 = (uint32_t)(r.s0 >> 32);
+  uint32_t b0 = (uint32_t)r.s1, b1 = (uint32_t)(r.s1 >> 32);
+  uint64_t result = r.s0 + r.s1;
+  b0 ^= a0;
+  b1 ^= a1;
+  /* rotl(s0, 55): lo = (lo >> 9) | (hi << 23), hi = (hi >> 9) | (lo << 23) */
+  uint32_t r0 = __builtin_amdgcn_alignbit(a1, a0, 9), r1 = __builtin_amdgcn_alignbit(a0, a1, 9);
+  /* s1 << 14 */
+  uint32_t t0 = b0 << 14, t1 = __builtin_amdgcn_alignbit(b1, b0, 18);
+  uint32_t n0 = r0 ^ b0 ^ t0, n1 = r1 ^ b1 ^ t1;
+  /* rotl(s1, 36) = rotl(swap halves, 4): hi = (lo << 4) | (hi >> 28), lo = (hi << 4) | (lo >> 28) */
+  uint32_t m1 = __builtin_amdgcn_alignbit(b0, b1, 28), m0 = __builtin_amdgcn_alignbit(b1, b0, 28);
+  r.s0 = ((uint64_t)n1 << 32) | n0;
+  r.s1 = ((uint64_t)m1 << 32) | m0;
   return result;
 }
 
@@ -66,12 +79,11 @@ DSD V3 cross3(const V3 &a, const V3 &b) {
   return c;
 }
 
-/* simulations.py:59-74 (three divides, not a reciprocal) */
+/* simulations.py:59-74: three divisions by the same length, evaluated with one
+ * division + exact residual corrections (ds_div3, same quotients) */
 DSD void normalize3(V3 &v) {
   double length = __builtin_sqrt(dot3(v, v));
-  v.x = v.x / length;
-  v.y = v.y / length;
-  v.z = v.z / length;
+  ds_div3(&v.x, &v.y, &v.z, length);
 }
 
 /* simulations.py:121-138 */

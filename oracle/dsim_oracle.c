@@ -149,7 +149,11 @@ static inline void cross3(const double *a, const double *b, double *c) {
 /* simulations.py:59-74 */
 static inline void normalize3(double *v) {
   double length = sqrt(dot3(v, v));
+#ifdef DSO_SHARED_MATH
+  ds_div3(&v[0], &v[1], &v[2], length); /* the product's evaluation of the same three quotients */
+#else
   for (int i = 0; i < 3; i++) v[i] = v[i] / length;
+#endif
 }
 
 /* simulations.py:77-97; triangle is (3,3) row-major */
@@ -669,5 +673,8 @@ void dso_u_subvoxel_range(const double *xs, int64_t n_xs, double x1, double x2, 
 uint64_t dso_u_next(dso_state *s) { return xoro_next(s); }
 double dso_u_uniform_f64(dso_state *s) { return uniform_f64(s); }
 float dso_u_logf(float x) { return DSO_LOGF(x); }
+#ifdef DSO_SHARED_MATH
+void dso_u_div3(double *v, double length) { ds_div3(&v[0], &v[1], &v[2], length); }
+#endif
 double dso_u_cos(double x) { return DSO_COS(x); }
 size_t dso_sizeof_geom(void) { return sizeof(dso_geom); }

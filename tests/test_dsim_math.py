@@ -32,3 +32,28 @@ def test_cos_0_2pi_within_1p5_ulp(oracle_exact):
     big = np.abs(ref) > 1e-6  # next to the zeros of cos only the ABSOLUTE error is bounded
     assert (err[big] / ulp[big]).max() < 1.6
     assert err.max() < 2e-16
+
+
+def test_div3_equals_ieee_division(oracle_exact):
+    """ds_div3 (one division + residual corrections) returns the IEEE quotients of the
+    reference's three divisions (simulations.py:72-73) on 3e6 random vectors, including
+    lengths with long runs of ones in the significand."""
+    import ctypes as C
+
+    lib = oracle_exact.lib
+    lib.dso_u_div3.argtypes = [C.POINTER(C.c_double), C.c_double]
+    rng = np.random.RandomState(4)
+    n = 1000000
+    v = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-8, 3, size=(n, 1))
+    length = np.sqrt((v * v).sum(axis=1))
+    length[::7] = np.nextafter(2.0 ** rng.randint(-20, 20, size=len(length[::7])), 0)  # 0x1.fff...p
+    want = v / length[:, None]
+    got = v.copy()
+    for i in range(n):
+        lib.dso_u_div3(got[i].ctypes.data_as(C.POINTER(C.c_double)), length[i])
+    assert np.array_equal(got, want)
+    for bad in (0.0, np.inf, np.nan):
+        g = np.array([1.0, 0.0, -2.0])
+        lib.dso_u_div3(g.ctypes.data_as(C.POINTER(C.c_double)), bad)
+        with np.errstate(all="ignore"):
+            np.testing.assert_array_equal(g, np.array([1.0, 0.0, -2.0]) / bad)
