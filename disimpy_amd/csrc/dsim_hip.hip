@@ -222,6 +222,7 @@ struct dsim_sim {
   int last_launches = 0;
   int block_size = 256, tile_steps = 0, meas_per_pass = 0;
   int resort_steps = 0; /* mesh: 0 = automatic, < 0 = never re-sort the walkers */
+  int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
   bool sort_ready = false;
   double *phase_alt = nullptr;
@@ -311,7 +312,7 @@ static int create_impl(dsim_sim *h, const double *gx, const double *gy, const do
   HIP_TRY(hipMemsetAsync(h->phase, 0, (size_t)h->M * n * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->exc, 0, n, h->stream));
   /* gradient re-laid-out [t][m][gx gy gz 0]: one contiguous, 16-byte aligned LDS tile per range of steps */
-  std::vector<double> g4((size_t)h->T * h->M * 4);
+  std::vector<double> g4((size_t)h->T * h->M * 4 + 32 * 4, 0.0); /* + 32 zero samples: scalar-path over-read */
   for (int m = 0; m < h->M; m++)
     for (int t = 0; t < h->T; t++) {
       size_t o = ((size_t)t * h->M + m) * 4;
@@ -359,7 +360,8 @@ extern "C" int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int6
   return DSIM_OK;
 }
 
-extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass, int32_t resort_steps) {
+extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass, int32_t resort_steps,
+                               int32_t gradient_source) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (block_size) {
     if (block_size < 64 || block_size > 256 || block_size % 64) return fail(DSIM_ERR_INVALID, "block_size must be 64, 128, 192 or 256");
@@ -368,6 +370,7 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
   if (tile_steps > 0) h->tile_steps = tile_steps;
   if (meas_per_pass > 0) h->meas_per_pass = meas_per_pass;
   if (resort_steps != 0) h->resort_steps = resort_steps;
+  if (gradient_source == 1 || gradient_source == 2) h->grad_src = gradient_source - 1;
   return DSIM_OK;
 }
 
@@ -662,20 +665,23 @@ extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_ve
 /* ------------------------------------------------------------------ launch --- */
 
 template <int GEOM, int MB>
-static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s) {
-  walk_kernel<GEOM, MB><<<grid, block, lds, s>>>(p);
+static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc) {
+  if (gsrc)
+    walk_kernel<GEOM, MB, 1><<<grid, block, lds, s>>>(p);
+  else
+    walk_kernel<GEOM, MB, 0><<<grid, block, lds, s>>>(p);
   return hipGetLastError();
 }
 
 template <int GEOM>
-static hipError_t launch_mb(int mb, const WalkParams &p, int grid, int block, size_t lds, hipStream_t s) {
+static hipError_t launch_mb(int mb, const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc) {
   switch (mb) {
-    case 1: return launch_one<GEOM, 1>(p, grid, block, lds, s);
-    case 2: return launch_one<GEOM, 2>(p, grid, block, lds, s);
-    case 4: return launch_one<GEOM, 4>(p, grid, block, lds, s);
-    case 8: return launch_one<GEOM, 8>(p, grid, block, lds, s);
-    case 16: return launch_one<GEOM, 16>(p, grid, block, lds, s);
-    default: return launch_one<GEOM, 32>(p, grid, block, lds, s);
+    case 1: return launch_one<GEOM, 1>(p, grid, block, lds, s, gsrc);
+    case 2: return launch_one<GEOM, 2>(p, grid, block, lds, s, gsrc);
+    case 4: return launch_one<GEOM, 4>(p, grid, block, lds, s, gsrc);
+    case 8: return launch_one<GEOM, 8>(p, grid, block, lds, s, gsrc);
+    case 16: return launch_one<GEOM, 16>(p, grid, block, lds, s, gsrc);
+    default: return launch_one<GEOM, 32>(p, grid, block, lds, s, gsrc);
   }
 }
 
@@ -825,11 +831,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       p.write_state = pass == passes - 1;
       hipError_t e;
       switch (geom) {
-        case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream); break;
-        case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream); break;
-        case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream); break;
-        case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream); break;
-        default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream); break;
+        case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
+        case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
+        case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
+        case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
+        default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
       }
       if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
       h->last_launches++;

@@ -341,7 +341,7 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
 
 /* ---- the fused kernel --------------------------------------------------------- */
 
-template <int GEOM, int MB>
+template <int GEOM, int MB, int GSRC>
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   extern __shared__ double lds[];
   double *log_tab = lds;                           /* 128 doubles                     */
@@ -377,18 +377,19 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
 
   for (int t0 = p.t_begin; t0 < p.t_end; t0 += p.tile_steps) {
     const int kt = min(p.tile_steps, p.t_end - t0);
-    __syncthreads(); /* previous tile fully consumed (also orders the table fills above) */
-    {
-      /* tile rows are contiguous runs of mc*4 doubles inside g4[t][M][4] */
+    if (GSRC == 0) {
+      __syncthreads(); /* previous tile fully consumed */
+      /* tile rows are contiguous runs of mc*4 doubles inside g4[t][M][4]; measurement slots
+       * beyond mc are zero-filled so that the accumulation loop needs no per-slot guard */
       const int row = p.mc * 2; /* double2 per step */
       const double2 *src = reinterpret_cast<const double2 *>(p.g4);
       double2 *dst = reinterpret_cast<double2 *>(gt);
-      for (int e = threadIdx.x; e < kt * row; e += blockDim.x) {
-        int k = e / row, c = e - k * row;
-        dst[k * (MB * 2) + c] = src[((int64_t)(t0 + k) * p.M + p.m0) * 2 + c];
+      for (int e = threadIdx.x; e < kt * (MB * 2); e += blockDim.x) {
+        int k = e / (MB * 2), c = e - k * (MB * 2);
+        dst[e] = c < row ? src[((int64_t)(t0 + k) * p.M + p.m0) * 2 + c] : make_double2(0.0, 0.0);
       }
     }
-    __syncthreads();
+    __syncthreads(); /* tile (and, the first time, the tables) visible */
     if (live) {
       for (int k = 0; k < kt; k++) {
         V3 step = random_step(rng, log_tab);
@@ -407,13 +408,23 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
           step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
         }
         /* phases[m, i] += GAMMA*dt*(gx*x + gy*y + gz*z), e.g. simulations.py:692-701 */
-        const double *g = gt + k * (MB * 4);
+        if (GSRC == 0) {
+          /* every lane reads the same LDS address: broadcast */
+          const double *g = gt + k * (MB * 4);
 #pragma unroll
-        for (int m = 0; m < MB; m++) {
-          if (m < p.mc) {
+          for (int m = 0; m < MB; m++) {
             double2 gxy = *reinterpret_cast<const double2 *>(g + m * 4);
             double gz = g[m * 4 + 2];
             double inner = __builtin_fma(gz, r.z, __builtin_fma(gxy.x, r.x, gxy.y * r.y));
+            ph[m] = __builtin_fma(p.gdt, inner, ph[m]);
+          }
+        } else {
+          /* wave-uniform address: the compiler emits scalar (SMEM) loads and the gradient
+           * samples feed the fp64 FMAs straight from SGPRs (g4 is padded by 32 samples) */
+          const double *g = p.g4 + ((int64_t)(t0 + k) * p.M + p.m0) * 4;
+#pragma unroll
+          for (int m = 0; m < MB; m++) {
+            double inner = __builtin_fma(g[m * 4 + 2], r.z, __builtin_fma(g[m * 4], r.x, g[m * 4 + 1] * r.y));
             ph[m] = __builtin_fma(p.gdt, inner, ph[m]);
           }
         }

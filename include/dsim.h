@@ -148,9 +148,11 @@ int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
 /* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
  * LDS gradient tile, measurements held in registers per pass, and - for mesh
  * substrates - the number of time steps between spatial re-sorts of the walker
- * slots (0 = automatic, negative = never; results do not depend on it). */
+ * slots (0 = automatic, negative = never), and where the kernels read the
+ * gradient samples from (1 = LDS tiles, 2 = scalar loads).  Results never
+ * depend on any of them. */
 int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass,
-                    int32_t resort_steps);
+                    int32_t resort_steps, int32_t gradient_source);
 
 #ifdef __cplusplus
 }
