@@ -60,11 +60,11 @@ DSD double rng_uniform_f64(Rng &r) { return u64_to_unit_f64(rng_next(r)); }
 DSD float rng_uniform_f32(Rng &r) { return (float)u64_to_unit_f64(rng_next(r)); }
 
 /* numba/cuda/random.py:199-221: float32 uniforms, float32 log, float64 rest */
-DSD double rng_normal_f64(Rng &r, const double *log_tab) {
+DSD double rng_normal_f64(Rng &r, const double *log_tab, const double *cos_tab) {
   float u1 = rng_uniform_f32(r);
   float u2 = rng_uniform_f32(r);
   double lg = (double)ds_logf(u1, log_tab);
-  return __builtin_sqrt(-2.0 * lg) * ds_cos_0_2pi(6.283185307179586 * (double)u2);
+  return __builtin_sqrt(-2.0 * lg) * ds_cos_0_2pi(6.283185307179586 * (double)u2, cos_tab);
 }
 
 /* simulations.py:23-36 */
@@ -87,11 +87,11 @@ DSD void normalize3(V3 &v) {
 }
 
 /* simulations.py:121-138 */
-DSD V3 random_step(Rng &r, const double *log_tab) {
+DSD V3 random_step(Rng &r, const double *log_tab, const double *cos_tab) {
   V3 s;
-  s.x = rng_normal_f64(r, log_tab);
-  s.y = rng_normal_f64(r, log_tab);
-  s.z = rng_normal_f64(r, log_tab);
+  s.x = rng_normal_f64(r, log_tab, cos_tab);
+  s.y = rng_normal_f64(r, log_tab, cos_tab);
+  s.z = rng_normal_f64(r, log_tab, cos_tab);
   normalize3(s);
   return s;
 }

@@ -783,7 +783,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
   p.tile_steps = tile;
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
-  size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);
+  size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);
   if (lds > 64 * 1024) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int block = h->block_size;
   const int grid = grid_for(h->n, block);

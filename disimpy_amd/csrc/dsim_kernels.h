@@ -6,7 +6,8 @@
  * simulations.py:1198-1216).  Per walker, position + xoroshiro128+ state + MB
  * phase accumulators stay in registers for the whole range; HBM is touched
  * once at the start and once at the end (SoA, one 8-byte lane per wavefront
- * lane => fully coalesced).  LDS holds (a) the 1 KB log table of ds_logf,
+ * lane => fully coalesced).  LDS holds (a) the 1 KB log table of ds_logf and
+ * the 4 KB cos/sin table of ds_cos_0_2pi,
  * (b) the subvoxel boundaries of the mesh index, (c) the current tile of the
  * gradient waveform, laid out [step][measurement][x y z pad] so that every lane
  * of a wavefront reads the same address (LDS broadcast, no bank conflict).
@@ -345,12 +346,14 @@ template <int GEOM, int MB, int GSRC>
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   extern __shared__ double lds[];
   double *log_tab = lds;                           /* 128 doubles                     */
-  double *bounds = lds + DS_LOG_TABLE_DOUBLES;     /* mesh only                       */
+  double *cos_tab = lds + DS_LOG_TABLE_DOUBLES;    /* 514 doubles                     */
+  double *bounds = cos_tab + DS_COS_TABLE_DOUBLES; /* mesh only                       */
   int n_bounds = 0;
   if (GEOM == GEOM_MESH) n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
   double *gt = bounds + ((n_bounds + 1) & ~1);     /* gradient tile, 16-byte aligned  */
 
   for (int i = threadIdx.x; i < DS_LOG_TABLE_DOUBLES; i += blockDim.x) log_tab[i] = ds_log_table_dev[i];
+  for (int i = threadIdx.x; i < DS_COS_TABLE_DOUBLES; i += blockDim.x) cos_tab[i] = ds_cos_table_dev[i];
   if (GEOM == GEOM_MESH)
     for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) bounds[i] = p.mesh.bounds[i];
   const double *xs = bounds, *ys = bounds + p.mesh.nx + 1, *zs = bounds + p.mesh.nx + p.mesh.ny + 2;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
     __syncthreads(); /* tile (and, the first time, the tables) visible */
     if (live) {
       for (int k = 0; k < kt; k++) {
-        V3 step = random_step(rng, log_tab);
+        V3 step = random_step(rng, log_tab, cos_tab);
         if (GEOM == GEOM_FREE) {
           /* simulations.py:690-691 */
           r.x = __builtin_fma(step.x, p.step_l, r.x);

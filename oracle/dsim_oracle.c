@@ -51,7 +51,7 @@
 #ifdef DSO_SHARED_MATH
 #include "../disimpy_amd/csrc/dsim_math.h"
 #define DSO_LOGF(x) ds_logf((x), ds_log_table_host)
-#define DSO_COS(x) ds_cos_0_2pi(x)
+#define DSO_COS(x) ds_cos_0_2pi((x), ds_cos_table_host)
 #else
 #define DSO_LOGF(x) logf(x)
 #define DSO_COS(x) cos(x)
