@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--tile-steps", type=int, default=0)
     ap.add_argument("--meas-per-pass", type=int, default=0)
     ap.add_argument("--gradient-source", type=int, default=0, help="1 = LDS tiles, 2 = scalar loads (0 = default)")
+    ap.add_argument("--mesh-traversal", type=int, default=0, help="1 = per lane, 2 = wavefront-cooperative")
     ap.add_argument("--resort-steps", type=int, default=0, help="mesh: steps between walker re-sorts (0 auto, <0 never)")
     args = ap.parse_args()
 
@@ -208,7 +209,8 @@ def main():
     np.random.seed(123)
     positions, frames = simulations._initial_positions(n_total, sub, 123, True, device)
     sim = _lib.Sim(n_local, gradient, dt, step_l, device=device, first_walker=a)
-    sim.set_tuning(args.block_size, args.tile_steps, args.meas_per_pass, args.resort_steps, args.gradient_source)
+    sim.set_tuning(args.block_size, args.tile_steps, args.meas_per_pass, args.resort_steps, args.gradient_source,
+                   args.mesh_traversal)
     t_rng = time.perf_counter()
     sim.rng_init_device(123)
     t_rng = time.perf_counter() - t_rng

@@ -73,7 +73,7 @@ def load():
     lib.dsim_triangle_box_overlap.argtypes = [_f64p, _f64p]
     lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
     lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
-    lib.dsim_set_tuning.argtypes = [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.dsim_set_tuning.argtypes = [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     _lib = lib
     return lib
 
@@ -199,9 +199,10 @@ class Sim:
         check(self._lib.dsim_set_mesh(self._h, p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs),
                                       p_i64(nsv), p_i64(svi), p_i64(tri), len(tri)))
 
-    def set_tuning(self, block_size=0, tile_steps=0, meas_per_pass=0, resort_steps=0, gradient_source=0):
+    def set_tuning(self, block_size=0, tile_steps=0, meas_per_pass=0, resort_steps=0, gradient_source=0,
+                   mesh_traversal=0):
         check(self._lib.dsim_set_tuning(self._h, block_size, tile_steps, meas_per_pass, resort_steps,
-                                        gradient_source))
+                                        gradient_source, mesh_traversal))
 
     # time loop ----------------------------------------------------------------
     def run_free(self, t0, t1):

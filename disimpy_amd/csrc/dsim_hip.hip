@@ -223,6 +223,7 @@ struct dsim_sim {
   int block_size = 256, tile_steps = 0, meas_per_pass = 0;
   int resort_steps = 0; /* mesh: 0 = automatic, < 0 = never re-sort the walkers */
   int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
+  int mesh_traversal = 0; /* 0/2 = wavefront-cooperative, 1 = per-lane */
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
   bool sort_ready = false;
   double *phase_alt = nullptr;
@@ -361,7 +362,7 @@ extern "C" int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int6
 }
 
 extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass, int32_t resort_steps,
-                               int32_t gradient_source) {
+                               int32_t gradient_source, int32_t mesh_traversal) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (block_size) {
     if (block_size < 64 || block_size > 256 || block_size % 64) return fail(DSIM_ERR_INVALID, "block_size must be 64, 128, 192 or 256");
@@ -371,6 +372,7 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
   if (meas_per_pass > 0) h->meas_per_pass = meas_per_pass;
   if (resort_steps != 0) h->resort_steps = resort_steps;
   if (gradient_source == 1 || gradient_source == 2) h->grad_src = gradient_source - 1;
+  if (mesh_traversal == 1 || mesh_traversal == 2) h->mesh_traversal = mesh_traversal;
   return DSIM_OK;
 }
 
@@ -665,23 +667,30 @@ extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_ve
 /* ------------------------------------------------------------------ launch --- */
 
 template <int GEOM, int MB>
-static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc) {
-  if (gsrc)
-    walk_kernel<GEOM, MB, 1><<<grid, block, lds, s>>>(p);
-  else
-    walk_kernel<GEOM, MB, 0><<<grid, block, lds, s>>>(p);
+static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {
+  if (GEOM == GEOM_MESH && coop) {
+    if (gsrc)
+      walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH><<<grid, block, lds, s>>>(p);
+    else
+      walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH><<<grid, block, lds, s>>>(p);
+  } else {
+    if (gsrc)
+      walk_kernel<GEOM, MB, 1, 0><<<grid, block, lds, s>>>(p);
+    else
+      walk_kernel<GEOM, MB, 0, 0><<<grid, block, lds, s>>>(p);
+  }
   return hipGetLastError();
 }
 
 template <int GEOM>
-static hipError_t launch_mb(int mb, const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc) {
+static hipError_t launch_mb(int mb, const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {
   switch (mb) {
-    case 1: return launch_one<GEOM, 1>(p, grid, block, lds, s, gsrc);
-    case 2: return launch_one<GEOM, 2>(p, grid, block, lds, s, gsrc);
-    case 4: return launch_one<GEOM, 4>(p, grid, block, lds, s, gsrc);
-    case 8: return launch_one<GEOM, 8>(p, grid, block, lds, s, gsrc);
-    case 16: return launch_one<GEOM, 16>(p, grid, block, lds, s, gsrc);
-    default: return launch_one<GEOM, 32>(p, grid, block, lds, s, gsrc);
+    case 1: return launch_one<GEOM, 1>(p, grid, block, lds, s, gsrc, coop);
+    case 2: return launch_one<GEOM, 2>(p, grid, block, lds, s, gsrc, coop);
+    case 4: return launch_one<GEOM, 4>(p, grid, block, lds, s, gsrc, coop);
+    case 8: return launch_one<GEOM, 8>(p, grid, block, lds, s, gsrc, coop);
+    case 16: return launch_one<GEOM, 16>(p, grid, block, lds, s, gsrc, coop);
+    default: return launch_one<GEOM, 32>(p, grid, block, lds, s, gsrc, coop);
   }
 }
 
@@ -782,10 +791,14 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   tile = std::min(tile, t_end - t_begin);
   tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
   p.tile_steps = tile;
+  const int coop = geom == GEOM_MESH && h->mesh_traversal != 1;
+  if (coop) tile = std::min(tile, std::max(1, 2048 / (mb * 32))); /* leave the LDS to the wave queues */
+  p.tile_steps = tile;
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
   size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);
-  if (lds > 64 * 1024) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int block = h->block_size;
+  if (coop) lds += (size_t)(block / 64) * sizeof(CoopWave);
+  if (lds > 64 * 1024) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int grid = grid_for(h->n, block);
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
   int resort = 0;
@@ -831,11 +844,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       p.write_state = pass == passes - 1;
       hipError_t e;
       switch (geom) {
-        case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
-        case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
-        case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
-        case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
-        default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream, h->grad_src); break;
+        case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
+        case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
+        case GEOM_CYLINDER: e = launch_mb<GEOM_CYLINDER>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
+        case GEOM_ELLIPSOID: e = launch_mb<GEOM_ELLIPSOID>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
+        default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
       }
       if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
       h->last_launches++;

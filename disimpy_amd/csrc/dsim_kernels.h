@@ -340,9 +340,11 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
   r0.z = __builtin_fma(step.z, step_l, r0.z);
 }
 
+#include "dsim_mesh_coop.h"
+
 /* ---- the fused kernel --------------------------------------------------------- */
 
-template <int GEOM, int MB, int GSRC>
+template <int GEOM, int MB, int GSRC, int COOP>
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   extern __shared__ double lds[];
   double *log_tab = lds;                           /* 128 doubles                     */
@@ -351,6 +353,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   int n_bounds = 0;
   if (GEOM == GEOM_MESH) n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
   double *gt = bounds + ((n_bounds + 1) & ~1);     /* gradient tile, 16-byte aligned  */
+  /* mesh, cooperative traversal: one CoopWave per wavefront behind the gradient tile */
+  CoopWave *coop = reinterpret_cast<CoopWave *>(gt + (size_t)p.tile_steps * MB * 4) + (threadIdx.x >> 6);
 
   for (int i = threadIdx.x; i < DS_LOG_TABLE_DOUBLES; i += blockDim.x) log_tab[i] = ds_log_table_dev[i];
   for (int i = threadIdx.x; i < DS_COS_TABLE_DOUBLES; i += blockDim.x) cos_tab[i] = ds_cos_table_dev[i];
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
       }
     }
     __syncthreads(); /* tile (and, the first time, the tables) visible */
-    if (live) {
+    if (live || (GEOM == GEOM_MESH && COOP)) { /* cooperative mesh traversal needs every lane of the wavefront */
       for (int k = 0; k < kt; k++) {
         V3 step = random_step(rng, log_tab, cos_tab);
         if (GEOM == GEOM_FREE) {
@@ -407,6 +411,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
           step_cylinder(r, step, p.step_l, p, exc);
         } else if (GEOM == GEOM_ELLIPSOID) {
           step_ellipsoid(r, step, p.step_l, p, exc);
+        } else if (COOP) {
+          step_mesh_coop(r, step, p.step_l, live, p, xs, ys, zs, rng, exc, coop, (int)(threadIdx.x & 63));
         } else {
           step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
         }

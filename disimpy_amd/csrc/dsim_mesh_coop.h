@@ -1,0 +1,326 @@
+/* dsim_mesh_coop.h - wavefront-cooperative traversal of the mesh index.
+ *
+ * Per-lane traversal (step_mesh in dsim_kernels.h) pays, at every loop level,
+ * for the slowest of the 64 lanes: measured on the neuron (tools/mesh_stats.py)
+ * a wavefront makes 47 record-batch trips per step with 8.6 lanes active and 45
+ * Moller-Trumbore trips with 2.2 lanes active.  Here the 64 walkers of a
+ * wavefront pool their candidate work in LDS:
+ *
+ *   stage 1  every walker ("owner") enumerates the micro-cells its segment
+ *            reaches and appends 4-record work items to the wave's item queue;
+ *   stage 2  all 64 lanes drain the queue round-robin - each item is 4 records
+ *            tested (float32 AABB + plane) against the OWNER's cull box read
+ *            from LDS; survivors are appended to the owner's survivor slots;
+ *   stage 3  every owner runs the fp64 Moller-Trumbore test on its own
+ *            survivors (1.5 per step on average) and keeps the minimum;
+ *   stage 4  reflection / crossing per walker, then the next iteration for
+ *            the walkers that hit something (simulations.py:924-997).
+ *
+ * Which triangles are tested, in fp64, against which ray is unchanged, and the
+ * minimum keeps the reference's "first visited wins a tie" rule through the
+ * explicit key (subvoxel visit number, position in the reference's list), so
+ * results stay bit-identical to step_mesh and to the oracle.  Anything that
+ * does not fit the queues (more than 255 subvoxels in range, image shifts
+ * beyond +-31 voxels, queue or slot overflow) is handled by the owner itself
+ * with the serial scan.
+ */
+#ifndef DSIM_MESH_COOP_H
+#define DSIM_MESH_COOP_H
+
+#define COOP_ITEM_CAP 384
+#define COOP_SURV_SLOTS 6
+
+struct CoopWave {
+  float4 box[64][4];                   /* lo.xyz hi.x | hi.yz a.xy | a.z e.xyz | tau          4 KB */
+  uint2 items[COOP_ITEM_CAP];          /* {first record | (count-1) << 30, owner|visit|shifts} 3 KB */
+  uint4 surv[64][COOP_SURV_SLOTS];     /* {triangle, list position, visit|shifts, 0}           6 KB */
+  int surv_n[64];
+  int n_items;
+  int pad[3];
+};
+
+DSD void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* cull box moved into the frame of a periodic image (shift subtracted), inflated by the
+ * float32 rounding of the subtraction; shift = 0 returns the box unchanged */
+DSD CullBox shift_cull_box(const CullBox &c, double shx, double shy, double shz) {
+  if (shx == 0 && shy == 0 && shz == 0) return c;
+  const float sx = (float)shx, sy = (float)shy, sz = (float)shz;
+  const float mx = 5e-7f * (__builtin_fabsf(sx) + __builtin_fmaxf(__builtin_fabsf(c.lox), __builtin_fabsf(c.hix)));
+  const float my = 5e-7f * (__builtin_fabsf(sy) + __builtin_fmaxf(__builtin_fabsf(c.loy), __builtin_fabsf(c.hiy)));
+  const float mz = 5e-7f * (__builtin_fabsf(sz) + __builtin_fmaxf(__builtin_fabsf(c.loz), __builtin_fabsf(c.hiz)));
+  CullBox o;
+  o.lox = c.lox - sx - mx;
+  o.loy = c.loy - sy - my;
+  o.loz = c.loz - sz - mz;
+  o.hix = c.hix - sx + mx;
+  o.hiy = c.hiy - sy + my;
+  o.hiz = c.hiz - sz + mz;
+  o.ax = c.ax - sx;
+  o.ay = c.ay - sy;
+  o.az = c.az - sz;
+  o.ex = c.ex - sx;
+  o.ey = c.ey - sy;
+  o.ez = c.ez - sz;
+  o.tau = c.tau + 4.0f * (mx + my + mz);
+  return o;
+}
+
+/* (visit, position) of the current best candidate; a candidate with an equal d wins only
+ * if it comes earlier in the reference's visiting order (simulations.py:937-983) */
+struct BestHit {
+  double d;
+  int visit, pos, tri;
+};
+
+DSD void offer_hit(BestHit &b, double d, int visit, int pos, int tri) {
+  if (d > 0 && (d < b.d || (d == b.d && (visit < b.visit || (visit == b.visit && pos < b.pos))))) {
+    b.d = d;
+    b.visit = visit;
+    b.pos = pos;
+    b.tri = tri;
+  }
+}
+
+DSD bool cull_record(const float4 &q0, const float4 &q1, const float4 &q2, const CullBox &cb) {
+  if (q0.x > cb.hix || q0.w < cb.lox || q0.y > cb.hiy || q1.x < cb.loy || q0.z > cb.hiz || q1.y < cb.loz) return true;
+  const float s0 = __builtin_fmaf(q2.x, cb.az, __builtin_fmaf(q1.z, cb.ax, q1.w * cb.ay)) - q2.y;
+  const float s1 = __builtin_fmaf(q2.x, cb.ez, __builtin_fmaf(q1.z, cb.ex, q1.w * cb.ey)) - q2.y;
+  return (s0 > cb.tau && s1 > cb.tau) || (s0 < -cb.tau && s1 < -cb.tau);
+}
+
+/* serial scan of one micro-cell by its owner (fallback path) */
+DSD void scan_cell_serial(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step, int visit,
+                          BestHit &best) {
+  for (int i = begin; i < end; i++) {
+    const float4 q0 = ms.mrec[3 * i], q1 = ms.mrec[3 * i + 1], q2 = ms.mrec[3 * i + 2];
+    if (cull_record(q0, q1, q2, cb)) continue;
+    const int ti = __float_as_int(q2.z), pos = __float_as_int(q2.w);
+    const double *rec = ms.tri + (int64_t)ti * 9;
+    double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
+    offer_hit(best, d, visit, pos, ti);
+  }
+}
+
+struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
+  int llx, lly, llz, ulx, uly, ulz;
+};
+
+/* Enumerate the subvoxels of the iteration in the reference's order.  MODE 0: owner
+ * pushes work items (falling back to serial scans when an item cannot be queued);
+ * MODE 1: everything serial. */
+template <int MODE>
+DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox &cb0, const V3 &r0, const V3 &step,
+                         const double *xs, const double *ys, const double *zs, CoopWave *W, int lane, BestHit &best) {
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
+  int visit = 0;
+  for (int xi = w.llx; xi < w.ulx; xi++) {
+    int x = xi, snx = 0;
+    if (x < 0 || x > nx - 1) {
+      snx = floor_div(x, nx);
+      x -= snx * nx;
+    }
+    const double shx = (double)snx * Lx;
+    for (int yi = w.lly; yi < w.uly; yi++) {
+      int y = yi, sny = 0;
+      if (y < 0 || y > ny - 1) {
+        sny = floor_div(y, ny);
+        y -= sny * ny;
+      }
+      const double shy = (double)sny * Ly;
+      for (int zi = w.llz; zi < w.ulz; zi++) {
+        int z = zi, snz = 0;
+        if (z < 0 || z > nz - 1) {
+          snz = floor_div(z, nz);
+          z -= snz * nz;
+        }
+        const double shz = (double)snz * Lz;
+        const int v = visit++;
+        const int sv = (x * ny + y) * nz + z;
+        const int2 mg = ms.sv_micro[sv];
+        if (mg.x == 0) continue; /* empty subvoxel */
+        const CullBox cb = shift_cull_box(cb0, shx, shy, shz);
+        const V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
+        const bool queueable = MODE == 0 && v < 256 && snx >= -32 && snx < 32 && sny >= -32 && sny < 32 && snz >= -32 && snz < 32;
+        const unsigned tag = (unsigned)lane | ((unsigned)v << 6) | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20) |
+                             ((unsigned)(snz + 32) << 26);
+        const int k = 1 << mg.y;
+        int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0;
+        if (mg.y != 0) {
+          const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
+          a0 = micro_cell((double)cb.lox, xs[x], sx, k);
+          a1 = micro_cell((double)cb.hix, xs[x], sx, k);
+          b0 = micro_cell((double)cb.loy, ys[y], sy, k);
+          b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
+          c0 = micro_cell((double)cb.loz, zs[z], sz, k);
+          c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+        }
+        for (int a = a0; a <= a1; a++)
+          for (int b = b0; b <= b1; b++)
+            for (int c = c0; c <= c1; c++) {
+              const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
+              const int cnt = cr.y - cr.x;
+              if (cnt <= 0) continue;
+              bool queued = false;
+              if (queueable) {
+                const int nb = (cnt + 3) >> 2;
+                const int base = atomicAdd(&W->n_items, nb);
+                if (base + nb <= COOP_ITEM_CAP) {
+                  for (int j = 0; j < nb; j++) {
+                    const int left = cnt - 4 * j;
+                    W->items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), tag);
+                  }
+                  queued = true;
+                } else {
+                  /* queue full: neutralise the part of the reservation that lies inside the queue */
+                  for (int j = base; j < COOP_ITEM_CAP && j < base + nb; j++) W->items[j] = make_uint2(0xffffffffu, 0u);
+                }
+              }
+              if (!queued) scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, v, best);
+            }
+      }
+    }
+  }
+}
+
+/* simulations.py:878-1002 for the 64 walkers of a wavefront together.  EVERY lane of the
+ * wavefront must call this (live = false for lanes without a walker). */
+DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkParams &p, const double *xs, const double *ys,
+                        const double *zs, Rng &rng, bool &exc, CoopWave *W, int lane) {
+  const MeshDev &ms = p.mesh;
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
+  int64_t iter_idx = 0;
+  bool check = live;
+  for (;;) {
+    const bool act = check && step_l > 0 && iter_idx < p.max_iter;
+    if (__ballot(act) == 0ULL) break;
+    if (lane == 0) W->n_items = 0;
+    W->surv_n[lane] = 0;
+    wave_sync();
+    BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0};
+    bool serial_all = false;
+    SubvoxelWalk sw = {0, 0, 0, 0, 0, 0};
+    CullBox cb0 = {};
+    /* ---- stage 1: owners enumerate their cells */
+    if (act) {
+      iter_idx++;
+      const double ex = __builtin_fma(step.x, step_l, r0.x);
+      const double ey = __builtin_fma(step.y, step_l, r0.y);
+      const double ez = __builtin_fma(step.z, step_l, r0.z);
+      sw.llx = ll_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+      sw.lly = ll_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+      sw.llz = ll_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+      sw.ulx = ul_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+      sw.uly = ul_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+      sw.ulz = ul_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+      cb0 = make_cull_box(r0, step, step_l);
+      const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
+      serial_all = nsub > 256;
+      if (serial_all) {
+        enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
+      } else {
+        W->box[lane][0] = make_float4(cb0.lox, cb0.loy, cb0.loz, cb0.hix);
+        W->box[lane][1] = make_float4(cb0.hiy, cb0.hiz, cb0.ax, cb0.ay);
+        W->box[lane][2] = make_float4(cb0.az, cb0.ex, cb0.ey, cb0.ez);
+        W->box[lane][3] = make_float4(cb0.tau, 0.f, 0.f, 0.f);
+        enumerate_cells<0>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
+      }
+    }
+    wave_sync();
+    /* ---- stage 2: all lanes drain the item queue */
+    {
+      const int n = min(W->n_items, COOP_ITEM_CAP);
+      for (int idx = lane; idx < n; idx += 64) {
+        const uint2 it = W->items[idx];
+        if (it.x == 0xffffffffu) continue;
+        const int first = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
+        const int owner = (int)(it.y & 63u);
+        const int snx = (int)((it.y >> 14) & 63u) - 32, sny = (int)((it.y >> 20) & 63u) - 32, snz = (int)(it.y >> 26) - 32;
+        const float4 f0 = W->box[owner][0], f1 = W->box[owner][1], f2 = W->box[owner][2], f3 = W->box[owner][3];
+        CullBox cb;
+        cb.lox = f0.x;
+        cb.loy = f0.y;
+        cb.loz = f0.z;
+        cb.hix = f0.w;
+        cb.hiy = f1.x;
+        cb.hiz = f1.y;
+        cb.ax = f1.z;
+        cb.ay = f1.w;
+        cb.az = f2.x;
+        cb.ex = f2.y;
+        cb.ey = f2.z;
+        cb.ez = f2.w;
+        cb.tau = f3.x;
+        cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        float4 q0[4], q1[4], q2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = first + min(u, cnt - 1);
+          q0[u] = ms.mrec[3 * j];
+          q1[u] = ms.mrec[3 * j + 1];
+          q2[u] = ms.mrec[3 * j + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb)) {
+            const int slot = atomicAdd(&W->surv_n[owner], 1);
+            if (slot < COOP_SURV_SLOTS)
+              W->surv[owner][slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
+          }
+        }
+      }
+    }
+    wave_sync();
+    /* ---- stage 3: owners test their survivors in fp64 */
+    if (act && !serial_all) {
+      const int ns = W->surv_n[lane];
+      if (ns > COOP_SURV_SLOTS) {
+        /* more survivors than slots: redo this walker's iteration serially (keeps every candidate) */
+        best.d = DS_INF;
+        best.visit = 0x7fffffff;
+        best.pos = 0x7fffffff;
+        enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
+      } else {
+        for (int s = 0; s < ns; s++) {
+          const uint4 sv = W->surv[lane][s];
+          const int visit = (int)((sv.z >> 6) & 255u);
+          const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
+          const V3 tr0 = {r0.x - (double)snx * Lx, r0.y - (double)sny * Ly, r0.z - (double)snz * Lz};
+          const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+          double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
+          offer_hit(best, d, visit, (int)sv.y, (int)sv.x);
+        }
+      }
+    }
+    /* ---- stage 4: resolve (simulations.py:986-997) */
+    if (act) {
+      if (best.d > step_l) {
+        check = false;
+      } else {
+        bool reflect = p.perm_prob < rng_uniform_f64(rng);
+        const double *rec = ms.tri + (int64_t)best.tri * 9;
+        V3 n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
+        normalize3(n);
+        if (reflect)
+          reflection(r0, step, best.d, n, p.eps);
+        else
+          crossing(r0, step, best.d, n, p.eps);
+        step_l -= best.d;
+      }
+    }
+  }
+  if (live) {
+    if (iter_idx >= p.max_iter) exc = true;
+    r0.x = __builtin_fma(step.x, step_l, r0.x);
+    r0.y = __builtin_fma(step.y, step_l, r0.y);
+    r0.z = __builtin_fma(step.z, step_l, r0.z);
+  }
+}
+
+#endif /* DSIM_MESH_COOP_H */

@@ -149,10 +149,11 @@ int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
  * LDS gradient tile, measurements held in registers per pass, and - for mesh
  * substrates - the number of time steps between spatial re-sorts of the walker
  * slots (0 = automatic, negative = never), and where the kernels read the
- * gradient samples from (1 = LDS tiles, 2 = scalar loads).  Results never
- * depend on any of them. */
+ * gradient samples from (1 = LDS tiles, 2 = scalar loads), how the mesh index is
+ * traversed (1 = per lane, 2 = wavefront-cooperative).  Results never depend on
+ * any of them. */
 int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass,
-                    int32_t resort_steps, int32_t gradient_source);
+                    int32_t resort_steps, int32_t gradient_source, int32_t mesh_traversal);
 
 #ifdef __cplusplus
 }

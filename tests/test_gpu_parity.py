@@ -285,7 +285,8 @@ def _mesh_arrays(sub):
 @pytest.mark.parametrize("periodic", [True, False])
 @pytest.mark.parametrize("n_sv", [[1, 1, 1], [1, 5, 20], [10, 10, 10]])
 @pytest.mark.parametrize("perm_prob", [0.0, 0.35])
-def test_mesh_bit_identical(lib, oracle_exact, periodic, n_sv, perm_prob):
+@pytest.mark.parametrize("traversal", [1, 2])  # per-lane / wavefront-cooperative traversal of the index
+def test_mesh_bit_identical(lib, oracle_exact, periodic, n_sv, perm_prob, traversal):
     from disimpy_amd import substrates
 
     m = golden("cylinder_mesh_closed.npz")
@@ -300,14 +301,14 @@ def test_mesh_bit_identical(lib, oracle_exact, periodic, n_sv, perm_prob):
     kw = dict(max_iter=1000, epsilon=1e-13, perm_prob=perm_prob)
     ma = _mesh_arrays(sub)
     ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 77, kw, mesh=ma)
-    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 77, kw, mesh=ma)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 77, kw, mesh=ma, tuning=dict(mesh_traversal=traversal))
     _assert_identical(gpu, ref)
     if not periodic and perm_prob == 0.0:
         assert (gpu["pos"] > 0).all() and (gpu["pos"] < sub.voxel_size).all()
 
 
-@pytest.mark.parametrize("resort_steps", [-1, 7, 0])
-def test_mesh_spatial_resorting_is_invisible(lib, oracle_exact, resort_steps):
+@pytest.mark.parametrize("resort_steps,traversal", [(-1, 2), (7, 2), (0, 2), (7, 1)])
+def test_mesh_spatial_resorting_is_invisible(lib, oracle_exact, resort_steps, traversal):
     """>= 4096 walkers: the mesh path re-sorts the walker slots by Morton key every few
     steps (tuning knob) and restores the order at the end; per-walker results must not move."""
     from disimpy_amd import substrates
@@ -322,12 +323,32 @@ def test_mesh_spatial_resorting_is_invisible(lib, oracle_exact, resort_steps):
     kw = dict(max_iter=1000, epsilon=1e-13)
     ma = _mesh_arrays(sub)
     ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma)
-    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma, tuning=dict(resort_steps=resort_steps),
-                   chunks=[0, 13, 40])
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma,
+                   tuning=dict(resort_steps=resort_steps, mesh_traversal=traversal), chunks=[0, 13, 40])
     _assert_identical(gpu, ref)
 
 
-def test_mesh_neuron_bit_identical_and_contained(lib, oracle_exact):
+def test_mesh_huge_steps_fall_back_to_serial_scans(lib, oracle_exact):
+    """Steps several voxels long (more than 256 subvoxels in range, periodic images): the
+    cooperative traversal hands such walkers to the serial path; results stay identical."""
+    from disimpy_amd import substrates
+
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 2e-6, n_sv=np.array([8, 8, 8]), quiet=True)
+    n, T, dt = 200, 12, 1e-1
+    step_l = float(np.sqrt(6 * D * dt))  # 35 um in a 14 um voxel
+    g = _random_gradient(1, T)
+    pos0 = np.random.RandomState(3).random_sample((n, 3)) * sub.voxel_size
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 9, kw, mesh=ma)
+    for traversal in (1, 2):
+        gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 9, kw, mesh=ma, tuning=dict(mesh_traversal=traversal))
+        _assert_identical(gpu, ref)
+
+
+@pytest.mark.parametrize("traversal", [1, 2])
+def test_mesh_neuron_bit_identical_and_contained(lib, oracle_exact, traversal):
     """The 29 688-triangle neuron of the reference's tests at the default 50^3 index."""
     from disimpy_amd import simulations, substrates
 
@@ -340,7 +361,7 @@ def test_mesh_neuron_bit_identical_and_contained(lib, oracle_exact):
     kw = dict(max_iter=1000, epsilon=1e-13)
     ma = _mesh_arrays(sub)
     ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma)
-    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma, tuning=dict(mesh_traversal=traversal))
     _assert_identical(gpu, ref)
     assert (gpu["pos"].max(axis=0) < sub.voxel_size).all() and (gpu["pos"].min(axis=0) > 0).all()
 

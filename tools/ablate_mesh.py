@@ -14,7 +14,7 @@ def run(label, sub, pos, n, T=2000, resort=0):
     gradient, dt = misst_waveform(10000, np.array([1e9]))
     step_l = float(np.sqrt(6 * 2e-9 * dt))
     with _lib.Sim(n, gradient, dt, step_l) as sim:
-        sim.set_tuning(0, 0, 0, resort, 0)
+        sim.set_tuning(0, 0, 0, resort, 0, 0)
         sim.rng_init_device(123)
         sim.set_positions(np.ascontiguousarray(pos))
         sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices,
