@@ -27,13 +27,13 @@
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
-#define COOP_ITEM_CAP 384
-#define COOP_SURV_SLOTS 6
+#define COOP_ITEM_CAP 256
+#define COOP_SURV_SLOTS 4
 
 struct CoopWave {
   float4 box[64][4];                   /* lo.xyz hi.x | hi.yz a.xy | a.z e.xyz | tau          4 KB */
-  uint2 items[COOP_ITEM_CAP];          /* {first record | (count-1) << 30, owner|visit|shifts} 3 KB */
-  uint4 surv[64][COOP_SURV_SLOTS];     /* {triangle, list position, visit|shifts, 0}           6 KB */
+  uint2 items[COOP_ITEM_CAP];          /* {first record | (count-1) << 30, owner|visit|shifts} 2 KB */
+  uint4 surv[64][COOP_SURV_SLOTS];     /* {triangle, list position, visit|shifts, 0}           4 KB */
   int surv_n[64];
   int n_items;
   int pad[3];
