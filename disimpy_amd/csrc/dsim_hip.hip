@@ -669,10 +669,15 @@ extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_ve
 template <int GEOM, int MB>
 static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {
   if (GEOM == GEOM_MESH && coop) {
+    /* the wave queues need more than the default 64 KB of dynamic LDS */
+    auto k1 = walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH>;
+    auto k0 = walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gsrc ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     if (gsrc)
-      walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH><<<grid, block, lds, s>>>(p);
+      k1<<<grid, block, lds, s>>>(p);
     else
-      walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH><<<grid, block, lds, s>>>(p);
+      k0<<<grid, block, lds, s>>>(p);
   } else {
     if (gsrc)
       walk_kernel<GEOM, MB, 1, 0><<<grid, block, lds, s>>>(p);
@@ -798,7 +803,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);
   const int block = h->block_size;
   if (coop) lds += (size_t)(block / 64) * sizeof(CoopWave);
-  if (lds > 64 * 1024) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
+  if (lds > (coop ? 160u : 64u) * 1024u) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int grid = grid_for(h->n, block);
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
   int resort = 0;

@@ -27,13 +27,13 @@
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
-#define COOP_ITEM_CAP 256
-#define COOP_SURV_SLOTS 4
+#define COOP_ITEM_CAP 512
+#define COOP_SURV_SLOTS 8
 
 struct CoopWave {
   float4 box[64][4];                   /* lo.xyz hi.x | hi.yz a.xy | a.z e.xyz | tau          4 KB */
-  uint2 items[COOP_ITEM_CAP];          /* {first record | (count-1) << 30, owner|visit|shifts} 2 KB */
-  uint4 surv[64][COOP_SURV_SLOTS];     /* {triangle, list position, visit|shifts, 0}           4 KB */
+  uint2 items[COOP_ITEM_CAP];          /* {first record | (count-1) << 30, owner|visit|shifts} 4 KB */
+  uint4 surv[64][COOP_SURV_SLOTS];     /* {triangle, list position, visit|shifts, 0}           8 KB */
   int surv_n[64];
   int n_items;
   int pad[3];
@@ -142,6 +142,8 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
         const double shz = (double)snz * Lz;
         const int v = visit++;
         const int sv = (x * ny + y) * nz + z;
+        STAT_LANE(1);
+        STAT_WAVE(1);
         const int2 mg = ms.sv_micro[sv];
         if (mg.x == 0) continue; /* empty subvoxel */
         const CullBox cb = shift_cull_box(cb0, shx, shy, shz);
@@ -181,7 +183,14 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
                   for (int j = base; j < COOP_ITEM_CAP && j < base + nb; j++) W->items[j] = make_uint2(0xffffffffu, 0u);
                 }
               }
-              if (!queued) scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, v, best);
+              if (!queued) {
+                STAT_LANE(8); /* cell scanned serially by its owner */
+                STAT_WAVE(8);
+                scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, v, best);
+              } else {
+                STAT_LANE(3);
+                STAT_WAVE(3);
+              }
             }
       }
     }
@@ -210,6 +219,8 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
     /* ---- stage 1: owners enumerate their cells */
     if (act) {
       iter_idx++;
+      STAT_LANE(0);
+      STAT_WAVE(0);
       const double ex = __builtin_fma(step.x, step_l, r0.x);
       const double ey = __builtin_fma(step.y, step_l, r0.y);
       const double ez = __builtin_fma(step.z, step_l, r0.z);
@@ -223,6 +234,8 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
       const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
       serial_all = nsub > 256;
       if (serial_all) {
+        STAT_LANE(10);
+        STAT_WAVE(10);
         enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
         W->box[lane][0] = make_float4(cb0.lox, cb0.loy, cb0.loz, cb0.hix);
@@ -237,6 +250,8 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
     {
       const int n = min(W->n_items, COOP_ITEM_CAP);
       for (int idx = lane; idx < n; idx += 64) {
+        STAT_LANE(4);
+        STAT_WAVE(4);
         const uint2 it = W->items[idx];
         if (it.x == 0xffffffffu) continue;
         const int first = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
@@ -282,12 +297,16 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
       const int ns = W->surv_n[lane];
       if (ns > COOP_SURV_SLOTS) {
         /* more survivors than slots: redo this walker's iteration serially (keeps every candidate) */
+        STAT_LANE(9);
+        STAT_WAVE(9);
         best.d = DS_INF;
         best.visit = 0x7fffffff;
         best.pos = 0x7fffffff;
         enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
         for (int s = 0; s < ns; s++) {
+          STAT_LANE(6);
+          STAT_WAVE(6);
           const uint4 sv = W->surv[lane][s];
           const int visit = (int)((sv.z >> 6) & 255u);
           const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;

@@ -13,7 +13,8 @@ from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
 NAMES = ["reflect-loop iterations", "subvoxels visited", "non-empty subvoxels", "micro-cells visited",
-         "record batches (4)", "records examined", "AABB pass -> fp64 test", "hits (reflections)"]
+         "record batches (4)", "records examined", "AABB pass -> fp64 test", "hits (reflections)",
+         "coop: cell scanned serially", "coop: survivor overflow redo", "coop: whole iteration serial"]
 
 
 def main():
