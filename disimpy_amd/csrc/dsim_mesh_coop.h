@@ -11,8 +11,9 @@
  *   stage 2  all 64 lanes drain the queue round-robin - each item is 4 records
  *            tested (float32 AABB + plane) against the OWNER's cull box read
  *            from LDS; survivors are appended to the owner's survivor slots;
- *   stage 3  every owner runs the fp64 Moller-Trumbore test on its own
- *            survivors (1.5 per step on average) and keeps the minimum;
+ *   stage 3  all lanes drain the survivor pool: fp64 Moller-Trumbore test with
+ *            the OWNER's ray (LDS), minimum per owner by 64-bit LDS atomics on
+ *            the bit pattern of d, ties resolved by a second atomic pass;
  *   stage 4  reflection / crossing per walker, then the next iteration for
  *            the walkers that hit something (simulations.py:924-997).
  *
@@ -21,22 +22,27 @@
  * explicit key (subvoxel visit number, position in the reference's list), so
  * results stay bit-identical to step_mesh and to the oracle.  Anything that
  * does not fit the queues (more than 255 subvoxels in range, image shifts
- * beyond +-31 voxels, queue or slot overflow) is handled by the owner itself
- * with the serial scan.
+ * beyond +-31 voxels, item queue or survivor pool overflow) is handled by the
+ * owner itself with the serial scan.
  */
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
-#define COOP_ITEM_CAP 512
-#define COOP_SURV_SLOTS 8
+#define COOP_ITEM_CAP 320
+#define COOP_SURV_CAP 256
 
 struct CoopWave {
-  float4 box[64][4];                   /* lo.xyz hi.x | hi.yz a.xy | a.z e.xyz | tau          4 KB */
-  uint2 items[COOP_ITEM_CAP];          /* {first record | (count-1) << 30, owner|visit|shifts} 4 KB */
-  uint4 surv[64][COOP_SURV_SLOTS];     /* {triangle, list position, visit|shifts, 0}           8 KB */
-  int surv_n[64];
-  int n_items;
-  int pad[3];
+  float box[64][13];                    /* owner's cull box: lo xyz, hi xyz, a xyz, e xyz, tau      3.3 KB */
+  double ray[64][6];                    /* owner's r0 xyz, step xyz (fp64, for the exact test)      3.0 KB */
+  unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)  0.5 KB */
+  unsigned long long best_key[64];      /* (visit << 32) | list position of the winner              0.5 KB */
+  int best_tri[64];                     /* its triangle                                                    */
+  int overflow[64];                     /* a survivor of this owner did not fit the pool                   */
+  uint2 items[COOP_ITEM_CAP];           /* {first record | (count-1) << 30, owner|visit|shifts}     2.5 KB */
+  uint4 surv[COOP_SURV_CAP];            /* {triangle, list position, owner|visit|shifts, 0}         4.0 KB */
+  double surv_d[COOP_SURV_CAP];         /* its distance, kept between the reduction passes          2.0 KB */
+  int n_items, n_surv;
+  int pad[2];
 };
 
 DSD void wave_sync() {
@@ -209,8 +215,13 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
   for (;;) {
     const bool act = check && step_l > 0 && iter_idx < p.max_iter;
     if (__ballot(act) == 0ULL) break;
-    if (lane == 0) W->n_items = 0;
-    W->surv_n[lane] = 0;
+    if (lane == 0) {
+      W->n_items = 0;
+      W->n_surv = 0;
+    }
+    W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
+    W->best_key[lane] = ~0ULL;
+    W->overflow[lane] = 0;
     wave_sync();
     BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0};
     bool serial_all = false;
@@ -238,10 +249,11 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         STAT_WAVE(10);
         enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
-        W->box[lane][0] = make_float4(cb0.lox, cb0.loy, cb0.loz, cb0.hix);
-        W->box[lane][1] = make_float4(cb0.hiy, cb0.hiz, cb0.ax, cb0.ay);
-        W->box[lane][2] = make_float4(cb0.az, cb0.ex, cb0.ey, cb0.ez);
-        W->box[lane][3] = make_float4(cb0.tau, 0.f, 0.f, 0.f);
+        float *bx = W->box[lane];
+        bx[0] = cb0.lox, bx[1] = cb0.loy, bx[2] = cb0.loz, bx[3] = cb0.hix, bx[4] = cb0.hiy, bx[5] = cb0.hiz;
+        bx[6] = cb0.ax, bx[7] = cb0.ay, bx[8] = cb0.az, bx[9] = cb0.ex, bx[10] = cb0.ey, bx[11] = cb0.ez, bx[12] = cb0.tau;
+        double *ry = W->ray[lane];
+        ry[0] = r0.x, ry[1] = r0.y, ry[2] = r0.z, ry[3] = step.x, ry[4] = step.y, ry[5] = step.z;
         enumerate_cells<0>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       }
     }
@@ -257,21 +269,10 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         const int first = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
         const int owner = (int)(it.y & 63u);
         const int snx = (int)((it.y >> 14) & 63u) - 32, sny = (int)((it.y >> 20) & 63u) - 32, snz = (int)(it.y >> 26) - 32;
-        const float4 f0 = W->box[owner][0], f1 = W->box[owner][1], f2 = W->box[owner][2], f3 = W->box[owner][3];
+        const float *bx = W->box[owner];
         CullBox cb;
-        cb.lox = f0.x;
-        cb.loy = f0.y;
-        cb.loz = f0.z;
-        cb.hix = f0.w;
-        cb.hiy = f1.x;
-        cb.hiz = f1.y;
-        cb.ax = f1.z;
-        cb.ay = f1.w;
-        cb.az = f2.x;
-        cb.ex = f2.y;
-        cb.ey = f2.z;
-        cb.ez = f2.w;
-        cb.tau = f3.x;
+        cb.lox = bx[0], cb.loy = bx[1], cb.loz = bx[2], cb.hix = bx[3], cb.hiy = bx[4], cb.hiz = bx[5];
+        cb.ax = bx[6], cb.ay = bx[7], cb.az = bx[8], cb.ex = bx[9], cb.ey = bx[10], cb.ez = bx[11], cb.tau = bx[12];
         cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
         float4 q0[4], q1[4], q2[4];
 #pragma unroll
@@ -284,19 +285,55 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb)) {
-            const int slot = atomicAdd(&W->surv_n[owner], 1);
-            if (slot < COOP_SURV_SLOTS)
-              W->surv[owner][slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
+            const int slot = atomicAdd(&W->n_surv, 1);
+            if (slot < COOP_SURV_CAP)
+              W->surv[slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
+            else
+              W->overflow[owner] = 1;
           }
         }
       }
     }
     wave_sync();
-    /* ---- stage 3: owners test their survivors in fp64 */
+    /* ---- stage 3: all lanes drain the survivor pool (fp64 tests), minimum per owner */
+    {
+      const int n = min(W->n_surv, COOP_SURV_CAP);
+      for (int idx = lane; idx < n; idx += 64) { /* pass A: distances, atomic minimum of d */
+        STAT_LANE(6);
+        STAT_WAVE(6);
+        const uint4 sv = W->surv[idx];
+        const int owner = (int)(sv.z & 63u);
+        const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
+        const double *ry = W->ray[owner];
+        const V3 tr0 = {ry[0] - (double)snx * Lx, ry[1] - (double)sny * Ly, ry[2] - (double)snz * Lz};
+        const V3 st = {ry[3], ry[4], ry[5]};
+        const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+        const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
+        W->surv_d[idx] = d;
+        if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
+      }
+      wave_sync();
+      for (int idx = lane; idx < n; idx += 64) { /* pass B: among equal d the earliest (visit, position) */
+        const uint4 sv = W->surv[idx];
+        const int owner = (int)(sv.z & 63u);
+        const double d = W->surv_d[idx];
+        if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner])
+          atomicMin(&W->best_key[owner], ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y);
+      }
+      wave_sync();
+      for (int idx = lane; idx < n; idx += 64) { /* pass C: the winner publishes its triangle */
+        const uint4 sv = W->surv[idx];
+        const int owner = (int)(sv.z & 63u);
+        const double d = W->surv_d[idx];
+        if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
+            ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner])
+          W->best_tri[owner] = (int)sv.x;
+      }
+      wave_sync();
+    }
     if (act && !serial_all) {
-      const int ns = W->surv_n[lane];
-      if (ns > COOP_SURV_SLOTS) {
-        /* more survivors than slots: redo this walker's iteration serially (keeps every candidate) */
+      if (W->overflow[lane]) {
+        /* a survivor was dropped: redo this walker's iteration serially (keeps every candidate) */
         STAT_LANE(9);
         STAT_WAVE(9);
         best.d = DS_INF;
@@ -304,16 +341,10 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         best.pos = 0x7fffffff;
         enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
-        for (int s = 0; s < ns; s++) {
-          STAT_LANE(6);
-          STAT_WAVE(6);
-          const uint4 sv = W->surv[lane][s];
-          const int visit = (int)((sv.z >> 6) & 255u);
-          const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
-          const V3 tr0 = {r0.x - (double)snx * Lx, r0.y - (double)sny * Ly, r0.z - (double)snz * Lz};
-          const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
-          double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
-          offer_hit(best, d, visit, (int)sv.y, (int)sv.x);
+        const unsigned long long bd = W->best_d[lane];
+        if (bd != 0x7ff0000000000000ULL) {
+          const unsigned long long key = W->best_key[lane];
+          offer_hit(best, __longlong_as_double((long long)bd), (int)(key >> 32), (int)(key & 0xffffffffu), W->best_tri[lane]);
         }
       }
     }
