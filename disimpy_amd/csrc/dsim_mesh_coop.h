@@ -28,8 +28,8 @@
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
-#define COOP_ITEM_CAP 320
-#define COOP_SURV_CAP 256
+#define COOP_ITEM_CAP 512
+#define COOP_SURV_CAP 192
 
 struct CoopWave {
   float box[64][13];                    /* owner's cull box: lo xyz, hi xyz, a xyz, e xyz, tau      3.3 KB */
