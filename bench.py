@@ -269,7 +269,8 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(args.workload, {}).get("bytes_per_launch")
+            if n_local == default_walkers[args.workload] and not args.meas_per_pass:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get("bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -283,7 +284,10 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 "
+            "FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated: profiles/hbm_traffic.json)",
+            "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
             "kernel": "walk_kernel<%s,%d>" % (sub.type, 1 << max(0, (meas_per_launch - 1).bit_length())),
             "algorithmic_bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch,
             "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
