@@ -193,6 +193,7 @@ struct DevMesh {
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
   float4 *mrec = nullptr;
+  float4 *tri_yz = nullptr;
   int2 *sv_micro = nullptr, *cell_range = nullptr;
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
@@ -240,6 +241,7 @@ static void free_mesh(DevMesh &m) {
   if (m.sv_range) (void)hipFree(m.sv_range);
   if (m.tri_idx) (void)hipFree(m.tri_idx);
   if (m.mrec) (void)hipFree(m.mrec);
+  if (m.tri_yz) (void)hipFree(m.tri_yz);
   if (m.sv_micro) (void)hipFree(m.sv_micro);
   if (m.cell_range) (void)hipFree(m.cell_range);
   if (m.bounds) (void)hipFree(m.bounds);
@@ -603,6 +605,21 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     }
     if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
   }
+  /* (y, z) extent of every triangle, float32 rounded outward by two ulps: cull box of the
+   * +x rays of fill_mesh_kernel */
+  std::vector<float4> tri_yz((size_t)n_faces);
+  for (int64_t f = 0; f < n_faces; f++) {
+    const int64_t *fc = &faces[(size_t)f * 3];
+    float lo[2], hi[2];
+    for (int ax = 1; ax < 3; ax++) {
+      double a = vertices[fc[0] * 3 + ax], b = vertices[fc[1] * 3 + ax], c = vertices[fc[2] * 3 + ax];
+      float l = (float)std::min(a, std::min(b, c)), h = (float)std::max(a, std::max(b, c));
+      const float ninf = -std::numeric_limits<float>::infinity(), pinf = std::numeric_limits<float>::infinity();
+      lo[ax - 1] = std::nextafter(std::nextafter(std::nextafter(l, ninf), ninf), ninf);
+      hi[ax - 1] = std::nextafter(std::nextafter(std::nextafter(h, pinf), pinf), pinf);
+    }
+    tri_yz[f] = make_float4(lo[0], lo[1], hi[0], hi[1]);
+  }
   std::vector<double> bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
   bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
@@ -610,6 +627,8 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&dm.tri_yz, tri_yz.size() * sizeof(float4)));
+  HIP_TRY(hipMemcpyAsync(dm.tri_yz, tri_yz.data(), tri_yz.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMalloc(&dm.mrec, mrec.size() * sizeof(float4)));
   HIP_TRY(hipMalloc(&dm.sv_micro, sv_micro.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.cell_range, cell_range.size() * sizeof(int2)));
@@ -641,6 +660,7 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
   m.mrec = dm.mrec;
+  m.tri_yz = dm.tri_yz;
   m.sv_micro = dm.sv_micro;
   m.cell_range = dm.cell_range;
   m.bounds = dm.bounds;
@@ -965,6 +985,28 @@ __global__ void fill_inf_kernel(double *px, double *py, double *pz, int64_t n) {
   }
 }
 
+__global__ void fill_flag_kernel(const double *px, int64_t n, int32_t *flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = px[i] != DS_INF ? 1 : 0;
+}
+
+/* accepted point i of this launch goes to row have + prefix[i] (rows beyond n are dropped) */
+__global__ void fill_scatter_kernel(const double *px, const double *py, const double *pz, const int32_t *flag, const int32_t *pref,
+                                    int64_t n, const int64_t *have, double *out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  int64_t row = *have + pref[i];
+  if (row < n) {
+    out[row * 3] = px[i];
+    out[row * 3 + 1] = py[i];
+    out[row * 3 + 2] = pz[i];
+  }
+}
+
+__global__ void fill_count_kernel(const int32_t *flag, const int32_t *pref, int64_t n, int64_t *have) {
+  *have += (int64_t)pref[n - 1] + flag[n - 1];
+}
+
 extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const double *vertices, int64_t n_vertices,
                               const int64_t *faces, int64_t n_faces, const double voxel_size[3], const double *xs,
                               const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
@@ -1028,33 +1070,67 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   for (int k = 0; k < 3; k++) fp.voxel[k] = voxel_size[k];
   fp.mesh = mesh_dev(dm);
   const size_t lds = (size_t)(dm.nx + dm.ny + dm.nz + 3) * sizeof(double);
-  std::vector<double> hx((size_t)n_points), hy((size_t)n_points), hz((size_t)n_points);
+  /* Accepted points are compacted ON THE DEVICE in thread order (simulations.py:573-576 keeps the
+   * finite rows of every launch in order): flags -> exclusive scan -> scatter into the output at
+   * offset `have`; only the running count crosses PCIe per launch. */
+  if (n_points >= (int64_t)INT32_MAX) {
+    cleanup();
+    return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: too many points");
+  }
+  int32_t *d_flag = nullptr, *d_pref = nullptr;
+  int64_t *d_have = nullptr;
+  double *d_out = nullptr;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  auto cleanup2 = [&]() {
+    if (d_flag) (void)hipFree(d_flag);
+    if (d_pref) (void)hipFree(d_pref);
+    if (d_have) (void)hipFree(d_have);
+    if (d_out) (void)hipFree(d_out);
+    if (d_tmp) (void)hipFree(d_tmp);
+    cleanup();
+  };
+#define FILL_TRY2(expr)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      cleanup2();                                                                          \
+      return fail(DSIM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));             \
+    }                                                                                      \
+  } while (0)
+  FILL_TRY2(hipMalloc(&d_flag, n_points * sizeof(int32_t)));
+  FILL_TRY2(hipMalloc(&d_pref, n_points * sizeof(int32_t)));
+  FILL_TRY2(hipMalloc(&d_have, sizeof(int64_t)));
+  FILL_TRY2(hipMalloc(&d_out, (size_t)n_points * 3 * sizeof(double)));
+  FILL_TRY2(hipMemsetAsync(d_have, 0, sizeof(int64_t), stream));
+  FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
+  FILL_TRY2(hipMalloc(&d_tmp, tmp_bytes));
   int64_t have = 0;
   int launches = 0;
   while (have < n_points) {
-    if (++launches > 100000) {
-      cleanup();
-      return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 100000 launches (is the surface closed?)");
+    if (++launches > 1000000) {
+      cleanup2();
+      return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
     }
     fill_inf_kernel<<<grid, 256, 0, stream>>>(px, py, pz, n_points);
-    FILL_TRY(hipGetLastError());
+    FILL_TRY2(hipGetLastError());
     fill_mesh_kernel<<<grid, 256, lds, stream>>>(fp);
-    FILL_TRY(hipGetLastError());
-    FILL_TRY(hipMemcpyAsync(hx.data(), px, n_points * sizeof(double), hipMemcpyDeviceToHost, stream));
-    FILL_TRY(hipMemcpyAsync(hy.data(), py, n_points * sizeof(double), hipMemcpyDeviceToHost, stream));
-    FILL_TRY(hipMemcpyAsync(hz.data(), pz, n_points * sizeof(double), hipMemcpyDeviceToHost, stream));
-    FILL_TRY(hipStreamSynchronize(stream));
-    /* keep finite rows in thread order (simulations.py:573-576) */
-    for (int64_t i = 0; i < n_points && have < n_points; i++)
-      if (!std::isinf(hx[i])) {
-        out_points[have * 3] = hx[i];
-        out_points[have * 3 + 1] = hy[i];
-        out_points[have * 3 + 2] = hz[i];
-        have++;
-      }
+    FILL_TRY2(hipGetLastError());
+    fill_flag_kernel<<<grid, 256, 0, stream>>>(px, n_points, d_flag);
+    FILL_TRY2(hipGetLastError());
+    FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
+    fill_scatter_kernel<<<grid, 256, 0, stream>>>(px, py, pz, d_flag, d_pref, n_points, d_have, d_out);
+    FILL_TRY2(hipGetLastError());
+    fill_count_kernel<<<1, 1, 0, stream>>>(d_flag, d_pref, n_points, d_have);
+    FILL_TRY2(hipGetLastError());
+    FILL_TRY2(hipMemcpyAsync(&have, d_have, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    FILL_TRY2(hipStreamSynchronize(stream));
   }
-  cleanup();
+  FILL_TRY2(hipMemcpyAsync(out_points, d_out, (size_t)n_points * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  FILL_TRY2(hipStreamSynchronize(stream));
+  cleanup2();
   return DSIM_OK;
+#undef FILL_TRY2
 #undef FILL_TRY
 }
 

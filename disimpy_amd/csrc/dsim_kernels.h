@@ -44,6 +44,7 @@ struct MeshDev {
   const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
                               AABB rounded outward, float32 supporting plane n.x = c, triangle index,
                               position in the reference's list */
+  const float4 *tri_yz;    /* [n_faces]     {miny minz maxy maxz} float32, rounded outward (fill kernel) */
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
   int ulz = ul_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
   int n_hits = 0;
   int32_t hits[FILL_MAX_HITS]; /* private (scratch) memory, like the reference's cuda.local.array(1000) */
+  const float fy = (float)pt.y, fz = (float)pt.z;
   for (int x = llx; x < ulx; x++)
     for (int y = lly; y < uly; y++)
       for (int z = llz; z < ulz; z++) {
@@ -691,6 +693,10 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
         for (int i = range.x; i < range.y; i++) {
           if (n_hits >= FILL_MAX_HITS) return; /* :478-479: sample abandoned */
           int ti = ms.tri_idx[i];
+          /* a +x ray can only meet a triangle whose (y, z) extent holds the point: skipping the
+           * others cannot change the hit count (the fp64 test would return NaN for them) */
+          const float4 yz = ms.tri_yz[ti];
+          if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
           const double *rec = ms.tri + (int64_t)ti * 9;
           double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
           if (d > 0) {
