@@ -263,3 +263,41 @@ def test_fill_mesh_statistics(api):
                 pts = simulations._fill_mesh(n_s, sub, False, seed=123) - (r + padding)
                 assert np.min(np.linalg.norm(pts, axis=1)) > 0.9 * r.min()
                 npt.assert_almost_equal(np.mean(pts, axis=0), np.zeros(3))
+
+
+def test_simulation_sharded_single_rank_rccl(api):
+    """disimpy_amd.sharding.simulation_sharded over a 1-rank RCCL ("nccl") process group on this
+    GPU equals simulation(); two shard ranges computed one after the other add up to the whole."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from disimpy_amd import sharding, simulations as sims
+
+    gradients, simulations, substrates = api
+    g, dt = example_gradient()
+    g = np.concatenate([g, 0.5 * g], axis=0)
+    n = 5000
+    want = simulations.simulation(n, D, g, dt, substrates.sphere(5e-6), quiet=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = sharding.simulation_sharded(n, D, g, dt, substrates.sphere(5e-6), dist=dist, device=0)
+        c, s_, nexc = sharding.reduce_signal(np.array([1.0, 2.0]), np.array([3.0, 4.0]), 5, dist, 0)
+    finally:
+        dist.destroy_process_group()
+    npt.assert_array_equal(got, want)
+    npt.assert_array_equal(c, [1.0, 2.0])
+    assert nexc == 5
+    # the same walkers as two shards (what ranks 0 and 1 of a 2-GPU run would compute)
+    np.random.seed(123)
+    parts = [sims._simulate(n, D, g, dt, substrates.sphere(5e-6), 123, None, True, 1000, 1e-13,
+                            walker_range=sharding.shard_range(n, r, 2)) for r in range(2)]
+    npt.assert_allclose(parts[0]["cos"] + parts[1]["cos"], want, rtol=0, atol=1e-9 * n)
