@@ -8,6 +8,11 @@ summation order.  The single collective is one all-reduce (sum, float64,
 2*M + 1 values: sum cos, sum sin, exceeded-walker count) over
 ``torch.distributed`` - backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
 CPU tests.  Payload <= ~1.6 KB: latency only, link bandwidth is irrelevant.
+
+Note: PyTorch wheels bundle their own HIP runtime.  In a process that uses both
+torch.cuda and this package, import torch BEFORE the first call into
+``disimpy_amd`` (bench.py and tests/conftest.py do), otherwise torch reports
+"No HIP GPUs are available".
 """
 import numpy as np
 

@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # PyTorch bundles its own HIP runtime: when both are used in one process (the sharding
+    import torch  # noqa: F401  tests), torch has to be imported BEFORE libdsim_hip.so is loaded
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
