@@ -368,6 +368,8 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   V3 r = {0, 0, 0};
   Rng rng = {1, 1};
   bool exc = false;
+  CellMemo memo;
+  memo_reset(memo);
   double ph[MB];
 #pragma unroll
   for (int m = 0; m < MB; m++) ph[m] = 0;
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
         } else if (GEOM == GEOM_ELLIPSOID) {
           step_ellipsoid(r, step, p.step_l, p, exc);
         } else if (COOP) {
-          step_mesh_coop(r, step, p.step_l, live, p, xs, ys, zs, rng, exc, coop, (int)(threadIdx.x & 63));
+          step_mesh_coop(r, step, p.step_l, live, p, xs, ys, zs, rng, exc, coop, (int)(threadIdx.x & 63), memo);
         } else {
           step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
         }
