@@ -373,7 +373,12 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
   if (tile_steps > 0) h->tile_steps = tile_steps;
   if (meas_per_pass > 0) h->meas_per_pass = meas_per_pass;
   if (resort_steps != 0) h->resort_steps = resort_steps;
-  if (gradient_source == 1 || gradient_source == 2) h->grad_src = gradient_source - 1;
+  if (gradient_source == 1 || gradient_source == 2) {
+#ifndef DSIM_SMEM_GRADIENT
+    if (gradient_source == 2) return fail(DSIM_ERR_INVALID, "scalar-load gradient path not built (compile with -DDSIM_SMEM_GRADIENT)");
+#endif
+    h->grad_src = gradient_source - 1;
+  }
   if (mesh_traversal == 1 || mesh_traversal == 2) h->mesh_traversal = mesh_traversal;
   return DSIM_OK;
 }
@@ -686,24 +691,32 @@ extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_ve
 
 /* ------------------------------------------------------------------ launch --- */
 
+/* The scalar-load (SMEM) gradient path was measured at half the speed of the LDS tiles
+ * (C2: 3.1e10 vs 6.0e10 spin-steps/s); its kernels are only instantiated when the library is
+ * built with -DDSIM_SMEM_GRADIENT (halves the build time otherwise). */
 template <int GEOM, int MB>
 static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {
   if (GEOM == GEOM_MESH && coop) {
     /* the wave queues need more than the default 64 KB of dynamic LDS */
-    auto k1 = walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH>;
     auto k0 = walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gsrc ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef DSIM_SMEM_GRADIENT
+    auto k1 = walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH>;
+    auto k = gsrc ? k1 : k0;
+#else
+    auto k = k0;
+#endif
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (gsrc)
-      k1<<<grid, block, lds, s>>>(p);
-    else
-      k0<<<grid, block, lds, s>>>(p);
+    k<<<grid, block, lds, s>>>(p);
   } else {
+#ifdef DSIM_SMEM_GRADIENT
     if (gsrc)
       walk_kernel<GEOM, MB, 1, 0><<<grid, block, lds, s>>>(p);
     else
+#endif
       walk_kernel<GEOM, MB, 0, 0><<<grid, block, lds, s>>>(p);
   }
+  (void)gsrc;
   return hipGetLastError();
 }
 

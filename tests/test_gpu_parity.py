@@ -158,9 +158,7 @@ def test_chunked_ranges_tiles_and_block_sizes_do_not_change_results(lib, oracle_
         (None, dict(block_size=64)),
         (None, dict(meas_per_pass=2)),  # 3 passes over the measurements: replays the walk
         ([0, 25, 50], dict(meas_per_pass=1, tile_steps=3, block_size=128)),
-        (None, dict(gradient_source=2)),  # gradient samples through scalar loads instead of LDS tiles
-        ([0, 7, 50], dict(gradient_source=2, meas_per_pass=4)),
-        (None, dict(gradient_source=1)),
+        (None, dict(gradient_source=1)),  # LDS tiles (the scalar-load variant needs -DDSIM_SMEM_GRADIENT)
     ]:
         gpu = _gpu_run(lib, FREE, n, g, dt, step_l, None, 9, chunks=chunks, tuning=tuning)
         _assert_identical(gpu, ref)
