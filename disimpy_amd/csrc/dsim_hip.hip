@@ -581,6 +581,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
             for (int c = c0[2]; c <= c1[2]; c++) cells[((size_t)a * k + b) * k + c].push_back(i);
       }
       sv_micro[s] = make_int2((int)cell_range.size(), lk);
+      if (lk == 0) sv_micro[s] = make_int2(-((int)(mrec.size() / 3) + 1), n_s); /* single cell: range inline */
       for (auto &cl : cells) {
         int start = (int)(mrec.size() / 3);
         for (int32_t i : cl) {

@@ -39,7 +39,8 @@ struct MeshDev {
   const double *tri;       /* [n_faces][9]  {A, E1, E2}                  */
   const int2 *sv_range;    /* [prod n_sv]   [start, end) into tri_idx    */
   const int32_t *tri_idx;  /* [n_refs]                                   */
-  const int2 *sv_micro;    /* [prod n_sv]   {first cell, log2 k}: micro-grid of the subvoxel        */
+  const int2 *sv_micro;    /* [prod n_sv]   {0,0} empty | {-(first record + 1), count}: one cell, inline |
+                              {first cell, log2 k}: micro-grid of k^3 cells                          */
   const int2 *cell_range;  /* [n_cells]     [start, end) into mrec                                  */
   const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
                               AABB rounded outward, float32 supporting plane n.x = c, triangle index,
@@ -296,11 +297,10 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
           V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
           const CullBox cb = make_cull_box(tr0, step, step_l);
           int pass_pos = INT_MIN;
-          if (mg.y == 0) {
+          if (mg.x < 0) { /* single-cell subvoxel: record range stored inline */
             STAT_LANE(3);
             STAT_WAVE(3);
-            const int2 cr = ms.cell_range[mg.x];
-            scan_candidates(ms, cr.x, cr.y, cb, tr0, step, min_d, closest, pass_pos);
+            scan_candidates(ms, -mg.x - 1, -mg.x - 1 + mg.y, cb, tr0, step, min_d, closest, pass_pos);
           } else {
             const int k = 1 << mg.y;
             const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;

@@ -112,6 +112,37 @@ DSD void scan_cell_serial(const MeshDev &ms, int begin, int end, const CullBox &
   }
 }
 
+/* One micro-cell [cr.x, cr.y) of records: queue it as 4-record items for the wavefront, or -
+ * when it cannot be queued - let the owner scan it now. */
+template <int MODE>
+DSD void emit_cell(const MeshDev &ms, int2 cr, bool queueable, unsigned tag, const CullBox &cb, const V3 &tr0, const V3 &step,
+                   int visit, CoopWave *W, BestHit &best) {
+  const int cnt = cr.y - cr.x;
+  bool queued = false;
+  if (MODE == 0 && queueable) {
+    const int nb = (cnt + 3) >> 2;
+    const int base = atomicAdd(&W->n_items, nb);
+    if (base + nb <= COOP_ITEM_CAP) {
+      for (int j = 0; j < nb; j++) {
+        const int left = cnt - 4 * j;
+        W->items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), tag);
+      }
+      queued = true;
+    } else {
+      /* queue full: neutralise the part of the reservation that lies inside the queue */
+      for (int j = base; j < COOP_ITEM_CAP && j < base + nb; j++) W->items[j] = make_uint2(0xffffffffu, 0u);
+    }
+  }
+  if (!queued) {
+    STAT_LANE(8); /* cell scanned serially by its owner */
+    STAT_WAVE(8);
+    scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, visit, best);
+  } else {
+    STAT_LANE(3);
+    STAT_WAVE(3);
+  }
+}
+
 struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
   int llx, lly, llz, ulx, uly, ulz;
 };
@@ -157,47 +188,36 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
         const bool queueable = MODE == 0 && v < 256 && snx >= -32 && snx < 32 && sny >= -32 && sny < 32 && snz >= -32 && snz < 32;
         const unsigned tag = (unsigned)lane | ((unsigned)v << 6) | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20) |
                              ((unsigned)(snz + 32) << 26);
-        const int k = 1 << mg.y;
-        int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0;
-        if (mg.y != 0) {
-          const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
-          a0 = micro_cell((double)cb.lox, xs[x], sx, k);
-          a1 = micro_cell((double)cb.hix, xs[x], sx, k);
-          b0 = micro_cell((double)cb.loy, ys[y], sy, k);
-          b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
-          c0 = micro_cell((double)cb.loz, zs[z], sz, k);
-          c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+        if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline */
+          emit_cell<MODE>(ms, make_int2(-mg.x - 1, -mg.x - 1 + mg.y), queueable, tag, cb, tr0, step, v, W, best);
+          continue;
         }
-        for (int a = a0; a <= a1; a++)
-          for (int b = b0; b <= b1; b++)
-            for (int c = c0; c <= c1; c++) {
-              const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
-              const int cnt = cr.y - cr.x;
-              if (cnt <= 0) continue;
-              bool queued = false;
-              if (queueable) {
-                const int nb = (cnt + 3) >> 2;
-                const int base = atomicAdd(&W->n_items, nb);
-                if (base + nb <= COOP_ITEM_CAP) {
-                  for (int j = 0; j < nb; j++) {
-                    const int left = cnt - 4 * j;
-                    W->items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), tag);
-                  }
-                  queued = true;
-                } else {
-                  /* queue full: neutralise the part of the reservation that lies inside the queue */
-                  for (int j = base; j < COOP_ITEM_CAP && j < base + nb; j++) W->items[j] = make_uint2(0xffffffffu, 0u);
-                }
+        const int k = 1 << mg.y;
+        const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
+        const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
+        const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
+        const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+        if (a1 - a0 < 2 && b1 - b0 < 2 && c1 - c0 < 2) {
+          /* the usual case (cull box within 2 cells per axis): the up to 8 cell ranges are
+           * requested together - one L2 round trip instead of one per cell */
+          int2 cr[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int da = j >> 2, db = (j >> 1) & 1, dc = j & 1;
+            const bool valid = a0 + da <= a1 && b0 + db <= b1 && c0 + dc <= c1;
+            cr[j] = valid ? ms.cell_range[mg.x + ((a0 + da) * k + (b0 + db)) * k + (c0 + dc)] : make_int2(0, 0);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (cr[j].y > cr[j].x) emit_cell<MODE>(ms, cr[j], queueable, tag, cb, tr0, step, v, W, best);
+        } else {
+          for (int a = a0; a <= a1; a++)
+            for (int b = b0; b <= b1; b++)
+              for (int c = c0; c <= c1; c++) {
+                const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
+                if (cr.y > cr.x) emit_cell<MODE>(ms, cr, queueable, tag, cb, tr0, step, v, W, best);
               }
-              if (!queued) {
-                STAT_LANE(8); /* cell scanned serially by its owner */
-                STAT_WAVE(8);
-                scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, v, best);
-              } else {
-                STAT_LANE(3);
-                STAT_WAVE(3);
-              }
-            }
+        }
       }
     }
   }
