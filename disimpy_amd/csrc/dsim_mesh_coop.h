@@ -197,20 +197,7 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
         const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
         const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
         const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
-        if (a1 - a0 < 2 && b1 - b0 < 2 && c1 - c0 < 2) {
-          /* the usual case (cull box within 2 cells per axis): the up to 8 cell ranges are
-           * requested together - one L2 round trip instead of one per cell */
-          int2 cr[8];
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int da = j >> 2, db = (j >> 1) & 1, dc = j & 1;
-            const bool valid = a0 + da <= a1 && b0 + db <= b1 && c0 + dc <= c1;
-            cr[j] = valid ? ms.cell_range[mg.x + ((a0 + da) * k + (b0 + db)) * k + (c0 + dc)] : make_int2(0, 0);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (cr[j].y > cr[j].x) emit_cell<MODE>(ms, cr[j], queueable, tag, cb, tr0, step, v, W, best);
-        } else {
+        {
           for (int a = a0; a <= a1; a++)
             for (int b = b0; b <= b1; b++)
               for (int c = c0; c <= c1; c++) {
