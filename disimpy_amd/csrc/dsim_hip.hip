@@ -12,7 +12,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -118,9 +120,7 @@ static HostRng matvec(const HostRng *cols, HostRng v) {
   return o;
 }
 
-static const JumpTables &jump_tables() {
-  static JumpTables jt;
-  if (jt.levels) return jt;
+static void build_jump_tables(JumpTables &jt) {
   const int L = 48;
   jt.cols.resize((size_t)L * 128);
   /* level 0: apply the reference's jump() to each basis vector */
@@ -132,6 +132,12 @@ static const JumpTables &jump_tables() {
   for (int k = 1; k < L; k++)
     for (int b = 0; b < 128; b++) jt.cols[(size_t)k * 128 + b] = matvec(&jt.cols[(size_t)(k - 1) * 128], jt.cols[(size_t)(k - 1) * 128 + b]);
   jt.levels = L;
+}
+
+static const JumpTables &jump_tables() {
+  static JumpTables jt;
+  static std::once_flag once;
+  std::call_once(once, build_jump_tables, std::ref(jt));
   return jt;
 }
 

@@ -301,3 +301,29 @@ def test_simulation_sharded_single_rank_rccl(api):
     parts = [sims._simulate(n, D, g, dt, substrates.sphere(5e-6), 123, None, True, 1000, 1e-13,
                             walker_range=sharding.shard_range(n, r, 2)) for r in range(2)]
     npt.assert_allclose(parts[0]["cos"] + parts[1]["cos"], want, rtol=0, atol=1e-9 * n)
+
+
+def test_c3_full_size_against_misst(api):
+    """BASELINE config C3 (impermeable sphere r = 5 um, 1e6 spins x 1e4 steps), accuracy run of
+    SURVEY.md 8d: 100 b-values of the reference's MISST waveform; the reference's own tolerance is
+    2 decimals at N = 1e5 (test_simulations.py:634) - at N = 1e6 and dt = 7 us the agreement is ~3e-3."""
+    gradients, simulations, substrates = api
+    g, dt = misst_gradient(gradients, False, n_t=10000)
+    n = int(1e6)
+    s = simulations.simulation(n, D, g, dt, substrates.sphere(5e-6), quiet=True)
+    misst = golden("misst_signals.npz")["sphere_30ms"]
+    assert np.abs(s / n - misst).max() < 5e-3
+
+
+def test_c5_scale_neuron_containment(api):
+    """BASELINE config C5 geometry at 1e5 intracellular walkers x 1e3 steps (re-sorted, cooperative
+    traversal): every walker ends inside the periodic voxel and none hits the iteration limit."""
+    gradients, simulations, substrates = api
+    m = golden("neuron_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), init_pos="intra", periodic=True, quiet=True)
+    g, dt = misst_gradient(gradients, False, n_t=1000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        s, pos = simulations.simulation(int(1e5), D, g[:2], dt, sub, final_pos=True, quiet=True)
+    assert np.all(np.max(pos, axis=0) < sub.voxel_size) and np.all(np.min(pos, axis=0) > 0)
+    assert np.all(np.isfinite(s)) and np.all(s / 1e5 <= 1.0) and s[0] / 1e5 > 0.99  # b = 1 s/m^2: no attenuation
