@@ -302,9 +302,10 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
       }
     }
     wave_sync();
-    /* ---- stage 2: all lanes drain the item queue */
-    {
-      const int n = min(W->n_items, COOP_ITEM_CAP);
+    /* ---- stage 2: all lanes drain the item queue (skipped by wavefronts in open space) */
+    const int n_queued = W->n_items;
+    if (n_queued > 0) {
+      const int n = min(n_queued, COOP_ITEM_CAP);
       for (int idx = lane; idx < n; idx += 64) {
         STAT_LANE(4);
         STAT_WAVE(4);
@@ -338,10 +339,11 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         }
       }
     }
-    wave_sync();
+    if (n_queued > 0) wave_sync();
     /* ---- stage 3: all lanes drain the survivor pool (fp64 tests), minimum per owner */
-    {
-      const int n = min(W->n_surv, COOP_SURV_CAP);
+    const int n_surviving = n_queued > 0 ? W->n_surv : 0;
+    if (n_surviving > 0) {
+      const int n = min(n_surviving, COOP_SURV_CAP);
       for (int idx = lane; idx < n; idx += 64) { /* pass A: distances, atomic minimum of d */
         STAT_LANE(6);
         STAT_WAVE(6);
