@@ -151,9 +151,8 @@ struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simu
  * pushes work items (falling back to serial scans when an item cannot be queued);
  * MODE 1: everything serial. */
 template <int MODE>
-DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, CullBox &cb0, bool &have_cb0, const V3 &r0, const V3 &step,
-                         double step_l, const double *xs, const double *ys, const double *zs, CoopWave *W, int lane,
-                         BestHit &best) {
+DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox &cb0, const V3 &r0, const V3 &step,
+                         const double *xs, const double *ys, const double *zs, CoopWave *W, int lane, BestHit &best) {
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
   int visit = 0;
@@ -184,19 +183,6 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, CullBox &cb0,
         STAT_WAVE(1);
         const int2 mg = ms.sv_micro[sv];
         if (mg.x == 0) continue; /* empty subvoxel */
-        if (!have_cb0) {
-          /* first non-empty subvoxel of this iteration: only now is the cull box worth its ~60 fp64
-           * operations; the owner also publishes box and ray for the lanes that will test its items */
-          cb0 = make_cull_box(r0, step, step_l);
-          have_cb0 = true;
-          if (MODE == 0) {
-            float *bx = W->box[lane];
-            bx[0] = cb0.lox, bx[1] = cb0.loy, bx[2] = cb0.loz, bx[3] = cb0.hix, bx[4] = cb0.hiy, bx[5] = cb0.hiz;
-            bx[6] = cb0.ax, bx[7] = cb0.ay, bx[8] = cb0.az, bx[9] = cb0.ex, bx[10] = cb0.ey, bx[11] = cb0.ez, bx[12] = cb0.tau;
-            double *ry = W->ray[lane];
-            ry[0] = r0.x, ry[1] = r0.y, ry[2] = r0.z, ry[3] = step.x, ry[4] = step.y, ry[5] = step.z;
-          }
-        }
         const CullBox cb = shift_cull_box(cb0, shx, shy, shz);
         const V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
         const bool queueable = MODE == 0 && v < 256 && snx >= -32 && snx < 32 && sny >= -32 && sny < 32 && snz >= -32 && snz < 32;
@@ -288,7 +274,6 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
     bool serial_all = false;
     SubvoxelWalk sw = {0, 0, 0, 0, 0, 0};
     CullBox cb0 = {};
-    bool have_cb0 = false;
     /* ---- stage 1: owners enumerate their cells */
     if (act) {
       iter_idx++;
@@ -300,14 +285,20 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
       axis_range(memo, 0, xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex, sw.llx, sw.ulx);
       axis_range(memo, 1, ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey, sw.lly, sw.uly);
       axis_range(memo, 2, zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez, sw.llz, sw.ulz);
+      cb0 = make_cull_box(r0, step, step_l);
       const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
       serial_all = nsub > 256;
       if (serial_all) {
         STAT_LANE(10);
         STAT_WAVE(10);
-        enumerate_cells<1>(ms, sw, cb0, have_cb0, r0, step, step_l, xs, ys, zs, W, lane, best);
+        enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
-        enumerate_cells<0>(ms, sw, cb0, have_cb0, r0, step, step_l, xs, ys, zs, W, lane, best);
+        float *bx = W->box[lane];
+        bx[0] = cb0.lox, bx[1] = cb0.loy, bx[2] = cb0.loz, bx[3] = cb0.hix, bx[4] = cb0.hiy, bx[5] = cb0.hiz;
+        bx[6] = cb0.ax, bx[7] = cb0.ay, bx[8] = cb0.az, bx[9] = cb0.ex, bx[10] = cb0.ey, bx[11] = cb0.ez, bx[12] = cb0.tau;
+        double *ry = W->ray[lane];
+        ry[0] = r0.x, ry[1] = r0.y, ry[2] = r0.z, ry[3] = step.x, ry[4] = step.y, ry[5] = step.z;
+        enumerate_cells<0>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       }
     }
     wave_sync();
@@ -394,7 +385,7 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         best.d = DS_INF;
         best.visit = 0x7fffffff;
         best.pos = 0x7fffffff;
-        enumerate_cells<1>(ms, sw, cb0, have_cb0, r0, step, step_l, xs, ys, zs, W, lane, best);
+        enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
         const unsigned long long bd = W->best_d[lane];
         if (bd != 0x7ff0000000000000ULL) {
