@@ -914,6 +914,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
 }
 
 #ifdef DSIM_STATS
+extern "C" int dsim_debug_ablate(int mode) {
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dsim_ablate), &mode, sizeof(int)));
+  return DSIM_OK;
+}
+
 /* development build only: read and clear the traversal counters */
 extern "C" int dsim_debug_stats(unsigned long long *out32) {
   HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(dsim_stats), 32 * sizeof(unsigned long long)));

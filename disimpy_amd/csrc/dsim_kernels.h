@@ -23,6 +23,11 @@
  * counts once per lane, STAT_WAVE once per wavefront that reaches the point. */
 #ifdef DSIM_STATS
 __device__ unsigned long long dsim_stats[32];
+/* ablation switch of the development build (results become wrong, only the timing is of interest):
+ * 1 = every subvoxel looks empty, 2 = cells are enumerated but nothing is queued or scanned,
+ * 3 = items are culled but survivors are dropped */
+__device__ int dsim_ablate = 0;
+#define ABLATE(n) (dsim_ablate == (n))
 #define STAT_LANE(i) atomicAdd(&dsim_stats[i], 1ULL)
 #define STAT_WAVE(i)                                                                         \
   do {                                                                                       \
@@ -31,6 +36,7 @@ __device__ unsigned long long dsim_stats[32];
 #else
 #define STAT_LANE(i)
 #define STAT_WAVE(i)
+#define ABLATE(n) false
 #endif
 
 enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };

@@ -118,6 +118,7 @@ template <int MODE>
 DSD void emit_cell(const MeshDev &ms, int2 cr, bool queueable, unsigned tag, const CullBox &cb, const V3 &tr0, const V3 &step,
                    int visit, CoopWave *W, BestHit &best) {
   const int cnt = cr.y - cr.x;
+  if (ABLATE(2)) return;
   bool queued = false;
   if (MODE == 0 && queueable) {
     const int nb = (cnt + 3) >> 2;
@@ -182,7 +183,7 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
         STAT_LANE(1);
         STAT_WAVE(1);
         const int2 mg = ms.sv_micro[sv];
-        if (mg.x == 0) continue; /* empty subvoxel */
+        if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel */
         const CullBox cb = shift_cull_box(cb0, shx, shy, shz);
         const V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
         const bool queueable = MODE == 0 && v < 256 && snx >= -32 && snx < 32 && sny >= -32 && sny < 32 && snz >= -32 && snz < 32;
@@ -329,7 +330,7 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb)) {
+          if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb) && !ABLATE(3)) {
             const int slot = atomicAdd(&W->n_surv, 1);
             if (slot < COOP_SURV_CAP)
               W->surv[slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
