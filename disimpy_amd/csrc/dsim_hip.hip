@@ -913,12 +913,14 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   return DSIM_OK;
 }
 
-#ifdef DSIM_STATS
+#ifdef DSIM_ABLATE
 extern "C" int dsim_debug_ablate(int mode) {
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dsim_ablate), &mode, sizeof(int)));
   return DSIM_OK;
 }
+#endif
 
+#ifdef DSIM_STATS
 /* development build only: read and clear the traversal counters */
 extern "C" int dsim_debug_stats(unsigned long long *out32) {
   HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(dsim_stats), 32 * sizeof(unsigned long long)));

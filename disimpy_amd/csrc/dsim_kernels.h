@@ -23,11 +23,7 @@
  * counts once per lane, STAT_WAVE once per wavefront that reaches the point. */
 #ifdef DSIM_STATS
 __device__ unsigned long long dsim_stats[32];
-/* ablation switch of the development build (results become wrong, only the timing is of interest):
- * 1 = every subvoxel looks empty, 2 = cells are enumerated but nothing is queued or scanned,
- * 3 = items are culled but survivors are dropped */
-__device__ int dsim_ablate = 0;
-#define ABLATE(n) (dsim_ablate == (n))
+
 #define STAT_LANE(i) atomicAdd(&dsim_stats[i], 1ULL)
 #define STAT_WAVE(i)                                                                         \
   do {                                                                                       \
@@ -36,6 +32,15 @@ __device__ int dsim_ablate = 0;
 #else
 #define STAT_LANE(i)
 #define STAT_WAVE(i)
+#endif
+
+/* Timing-ablation switch (-DDSIM_ABLATE, tools/ablate_coop.py; results become wrong, only the
+ * timing is of interest): 1 = every subvoxel looks empty, 2 = cells are enumerated but nothing
+ * is queued or scanned, 3 = items are culled but survivors are dropped. */
+#ifdef DSIM_ABLATE
+__device__ int dsim_ablate = 0;
+#define ABLATE(n) (dsim_ablate == (n))
+#else
 #define ABLATE(n) false
 #endif
 

@@ -1,8 +1,6 @@
 """Timing ablation of the cooperative mesh traversal (development build, GPU box):
-    make -C disimpy_amd/csrc libdsim_hip_stats.so
-    DSIM_LIB=disimpy_amd/csrc/libdsim_hip_stats.so python tools/ablate_coop.py [c5|c4]
-The event counters of the stats build cost time too, so only the DIFFERENCES between the
-modes are meaningful."""
+    make -C disimpy_amd/csrc libdsim_hip_ablate.so
+    DSIM_LIB=disimpy_amd/csrc/libdsim_hip_ablate.so python tools/ablate_coop.py [c5|c4]"""
 import os
 import sys
 
