@@ -837,7 +837,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
   p.tile_steps = tile;
   const int coop = geom == GEOM_MESH && h->mesh_traversal != 1;
-  if (coop) tile = std::min(tile, std::max(1, 1024 / (mb * 32))); /* leave the LDS to the wave queues */
+  if (coop) tile = std::min(tile, std::max(1, 4096 / (mb * 32))); /* leave the LDS to the wave queues */
   p.tile_steps = tile;
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
   size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);

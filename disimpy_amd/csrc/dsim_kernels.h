@@ -411,7 +411,54 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
       }
     }
     __syncthreads(); /* tile (and, the first time, the tables) visible */
-    if (live || (GEOM == GEOM_MESH && COOP)) { /* cooperative mesh traversal needs every lane of the wavefront */
+    if (GEOM == GEOM_MESH && COOP) {
+      /* Cooperative mesh traversal: every lane of the wavefront takes part in every pass, but each
+       * walker runs through the kt time steps of the tile at its own pace (k_lane): a walker that
+       * reflects needs further passes for the same step while its neighbours already start the
+       * next one.  Per walker the sequence of operations (RNG draws included) is unchanged. */
+      const int lane = (int)(threadIdx.x & 63);
+      int k_lane = 0;
+      bool in_step = false;
+      V3 step = {0, 0, 0};
+      double sl = 0;
+      int64_t iter_idx = 0;
+      for (;;) {
+        const bool want = live && k_lane < kt;
+        if (__ballot(want) == 0ULL) break;
+        if (want && !in_step) {
+          step = random_step(rng, log_tab, cos_tab);
+          sl = p.step_l;
+          iter_idx = 0;
+          in_step = true;
+        }
+        const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, p, xs, ys, zs, rng, coop, lane, memo);
+        if (in_step && finished) {
+          if (iter_idx >= p.max_iter) exc = true; /* simulations.py:999-1002 */
+          r.x = __builtin_fma(step.x, sl, r.x);
+          r.y = __builtin_fma(step.y, sl, r.y);
+          r.z = __builtin_fma(step.z, sl, r.z);
+          if (GSRC == 0) {
+            const double *g = gt + k_lane * (MB * 4);
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+              double2 gxy = *reinterpret_cast<const double2 *>(g + m * 4);
+              double gz = g[m * 4 + 2];
+              double inner = __builtin_fma(gz, r.z, __builtin_fma(gxy.x, r.x, gxy.y * r.y));
+              ph[m] = __builtin_fma(p.gdt, inner, ph[m]);
+            }
+          } else {
+            const double *g = p.g4 + ((int64_t)(t0 + k_lane) * p.M + p.m0) * 4;
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+              double inner = __builtin_fma(g[m * 4 + 2], r.z, __builtin_fma(g[m * 4], r.x, g[m * 4 + 1] * r.y));
+              ph[m] = __builtin_fma(p.gdt, inner, ph[m]);
+            }
+          }
+          k_lane++;
+          in_step = false;
+        }
+      }
+    } else if (live) {
       for (int k = 0; k < kt; k++) {
         V3 step = random_step(rng, log_tab, cos_tab);
         if (GEOM == GEOM_FREE) {
@@ -425,8 +472,6 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
           step_cylinder(r, step, p.step_l, p, exc);
         } else if (GEOM == GEOM_ELLIPSOID) {
           step_ellipsoid(r, step, p.step_l, p, exc);
-        } else if (COOP) {
-          step_mesh_coop(r, step, p.step_l, live, p, xs, ys, zs, rng, exc, coop, (int)(threadIdx.x & 63), memo);
         } else {
           step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
         }

@@ -251,18 +251,23 @@ DSD void axis_range(CellMemo &m, int k, const double *xs, int n, double inv_h, d
   }
 }
 
-/* simulations.py:878-1002 for the 64 walkers of a wavefront together.  EVERY lane of the
- * wavefront must call this (live = false for lanes without a walker). */
-DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkParams &p, const double *xs, const double *ys,
-                        const double *zs, Rng &rng, bool &exc, CoopWave *W, int lane, CellMemo &memo) {
+/* ONE pass of the reflect loop of simulations.py:924-997 for the 64 walkers of a wavefront
+ * together.  EVERY lane of the wavefront must call this; in_step marks the lanes whose walker
+ * is inside a time step.  Returns true for the lanes whose step is over after this pass (no
+ * hit within the remaining length, or the loop condition `step_l > 0 and iter_idx < max_iter`
+ * no longer holds).  The caller lets every lane run through its own time steps at its own pace
+ * (a wavefront then needs about mean-iterations-per-step passes per step, not the maximum over
+ * its 64 lanes). */
+DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, const WalkParams &p, const double *xs,
+                        const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane, CellMemo &memo) {
   const MeshDev &ms = p.mesh;
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
-  int64_t iter_idx = 0;
-  bool check = live;
-  for (;;) {
-    const bool act = check && step_l > 0 && iter_idx < p.max_iter;
-    if (__ballot(act) == 0ULL) break;
+  bool finished = false;
+  {
+    const bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
+    if (in_step && !act) finished = true; /* while-condition false on entry */
+    if (__ballot(act) == 0ULL) return finished;
     if (lane == 0) {
       W->n_items = 0;
       W->n_surv = 0;
@@ -398,7 +403,7 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
     /* ---- stage 4: resolve (simulations.py:986-997) */
     if (act) {
       if (best.d > step_l) {
-        check = false;
+        finished = true; /* check_intersection = False */
       } else {
         bool reflect = p.perm_prob < rng_uniform_f64(rng);
         const double *rec = ms.tri + (int64_t)best.tri * 9;
@@ -409,15 +414,11 @@ DSD void step_mesh_coop(V3 &r0, V3 &step, double step_l, bool live, const WalkPa
         else
           crossing(r0, step, best.d, n, p.eps);
         step_l -= best.d;
+        if (!(step_l > 0 && iter_idx < p.max_iter)) finished = true; /* the while-condition of the next pass */
       }
     }
   }
-  if (live) {
-    if (iter_idx >= p.max_iter) exc = true;
-    r0.x = __builtin_fma(step.x, step_l, r0.x);
-    r0.y = __builtin_fma(step.y, step_l, r0.y);
-    r0.z = __builtin_fma(step.z, step_l, r0.z);
-  }
+  return finished;
 }
 
 #endif /* DSIM_MESH_COOP_H */
