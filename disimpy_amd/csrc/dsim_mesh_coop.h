@@ -37,6 +37,7 @@ struct CoopWave {
   unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)  0.5 KB */
   unsigned long long best_key[64];      /* (visit << 32) | list position of the winner              0.5 KB */
   int best_tri[64];                     /* its triangle                                                    */
+  double best_n[64][3];                 /* E1 x E2 of that triangle (un-normalised normal)          1.5 KB */
   int overflow[64];                     /* a survivor of this owner did not fit the pool                   */
   uint2 items[COOP_ITEM_CAP];           /* {first record | (count-1) << 30, owner|visit|shifts}     2.5 KB */
   uint4 surv[COOP_SURV_CAP];            /* {triangle, list position, owner|visit|shifts, 0}         4.0 KB */
@@ -81,6 +82,8 @@ DSD CullBox shift_cull_box(const CullBox &c, double shx, double shy, double shz)
 struct BestHit {
   double d;
   int visit, pos, tri;
+  bool have_n; /* n holds E1 x E2 of tri (published by the lane that tested it) */
+  V3 n;
 };
 
 DSD void offer_hit(BestHit &b, double d, int visit, int pos, int tri) {
@@ -89,6 +92,7 @@ DSD void offer_hit(BestHit &b, double d, int visit, int pos, int tri) {
     b.visit = visit;
     b.pos = pos;
     b.tri = tri;
+    b.have_n = false;
   }
 }
 
@@ -276,7 +280,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     W->best_key[lane] = ~0ULL;
     W->overflow[lane] = 0;
     wave_sync();
-    BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0};
+    BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0, false, {0, 0, 0}};
     bool serial_all = false;
     SubvoxelWalk sw = {0, 0, 0, 0, 0, 0};
     CullBox cb0 = {};
@@ -378,8 +382,16 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const int owner = (int)(sv.z & 63u);
         const double d = W->surv_d[idx];
         if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
-            ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner])
+            ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner]) {
           W->best_tri[owner] = (int)sv.x;
+          /* the record is still in the vector L1: publish E1 x E2 so that the owner does not
+           * have to fetch the triangle again before it can reflect */
+          const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+          const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
+          W->best_n[owner][0] = nn.x;
+          W->best_n[owner][1] = nn.y;
+          W->best_n[owner][2] = nn.z;
+        }
       }
       wave_sync();
     }
@@ -396,7 +408,15 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const unsigned long long bd = W->best_d[lane];
         if (bd != 0x7ff0000000000000ULL) {
           const unsigned long long key = W->best_key[lane];
-          offer_hit(best, __longlong_as_double((long long)bd), (int)(key >> 32), (int)(key & 0xffffffffu), W->best_tri[lane]);
+          const double d_pool = __longlong_as_double((long long)bd);
+          const int v_pool = (int)(key >> 32), p_pool = (int)(key & 0xffffffffu);
+          offer_hit(best, d_pool, v_pool, p_pool, W->best_tri[lane]);
+          if (best.d == d_pool && best.visit == v_pool && best.pos == p_pool) { /* the pool's winner is the overall winner */
+            best.have_n = true;
+            best.n.x = W->best_n[lane][0];
+            best.n.y = W->best_n[lane][1];
+            best.n.z = W->best_n[lane][2];
+          }
         }
       }
     }
@@ -406,8 +426,11 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         finished = true; /* check_intersection = False */
       } else {
         bool reflect = p.perm_prob < rng_uniform_f64(rng);
-        const double *rec = ms.tri + (int64_t)best.tri * 9;
-        V3 n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
+        V3 n = best.n;
+        if (!best.have_n) {
+          const double *rec = ms.tri + (int64_t)best.tri * 9;
+          n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
+        }
         normalize3(n);
         if (reflect)
           reflection(r0, step, best.d, n, p.eps);
