@@ -379,8 +379,6 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   V3 r = {0, 0, 0};
   Rng rng = {1, 1};
   bool exc = false;
-  CellMemo memo;
-  memo_reset(memo);
   double ph[MB];
 #pragma unroll
   for (int m = 0; m < MB; m++) ph[m] = 0;
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
           iter_idx = 0;
           in_step = true;
         }
-        const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, p, xs, ys, zs, rng, coop, lane, memo);
+        const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, p, xs, ys, zs, rng, coop, lane);
         if (in_step && finished) {
           if (iter_idx >= p.max_iter) exc = true; /* simulations.py:999-1002 */
           r.x = __builtin_fma(step.x, sl, r.x);

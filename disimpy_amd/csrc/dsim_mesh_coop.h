@@ -215,44 +215,19 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
   }
 }
 
-/* Per-walker memo of the subvoxel it was last seen in (per axis: index c and the boundaries
- * xs[c], xs[c+1]).  If both end points of a segment lie STRICTLY between the two boundaries
- * of a primary-image cell, the reference's lookups (simulations.py:616-679) give ll = c and
- * ul = c + 1: floor(x / voxel) is 0 for 0 < x < voxel, the shifted coordinate is x itself,
- * and the two scans stop at c + 1.  Only a shortcut: a miss takes the full lookup. */
-struct CellMemo {
-  int c[3];
-  double lo[3], hi[3];
-};
-
-DSD void memo_reset(CellMemo &m) {
-  for (int k = 0; k < 3; k++) {
-    m.c[k] = -1;
-    m.lo[k] = DS_INF;
-    m.hi[k] = -DS_INF;
-  }
-}
-
-DSD void axis_range(CellMemo &m, int k, const double *xs, int n, double inv_h, double inv_l, double a, double e, int &ll, int &ul) {
-  const double mn = a < e ? a : e, mx = a > e ? a : e;
-  if (mn > m.lo[k] && mx < m.hi[k]) {
-    ll = m.c[k];
-    ul = ll + 1;
-    return;
-  }
-  ll = ll_subvoxel_overlap_periodic(xs, n, inv_h, inv_l, a, e);
-  ul = ul_subvoxel_overlap_periodic(xs, n, inv_h, inv_l, a, e);
-  /* remember the cell of the far end of the segment (where the walker is heading) */
-  const int ce = e >= a ? ul - 1 : ll;
-  if (ce >= 0 && ce < n && ul > ll) {
-    m.c[k] = ce;
-    m.lo[k] = xs[ce];
-    m.hi[k] = xs[ce + 1];
-  } else {
-    m.c[k] = -1;
-    m.lo[k] = DS_INF;
-    m.hi[k] = -DS_INF;
-  }
+/* subvoxel ranges (simulations.py:929-934) and cull box of the remaining segment */
+DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double step_l, const double *xs, const double *ys,
+                       const double *zs, SubvoxelWalk &sw, CullBox &cb0) {
+  const double ex = __builtin_fma(step.x, step_l, r0.x);
+  const double ey = __builtin_fma(step.y, step_l, r0.y);
+  const double ez = __builtin_fma(step.z, step_l, r0.z);
+  sw.llx = ll_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+  sw.lly = ll_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+  sw.llz = ll_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+  sw.ulx = ul_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+  sw.uly = ul_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+  sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+  cb0 = make_cull_box(r0, step, step_l);
 }
 
 /* ONE pass of the reflect loop of simulations.py:924-997 for the 64 walkers of a wavefront
@@ -263,7 +238,7 @@ DSD void axis_range(CellMemo &m, int k, const double *xs, int n, double inv_h, d
  * (a wavefront then needs about mean-iterations-per-step passes per step, not the maximum over
  * its 64 lanes). */
 DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, const WalkParams &p, const double *xs,
-                        const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane, CellMemo &memo) {
+                        const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
   const MeshDev &ms = p.mesh;
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
@@ -282,20 +257,14 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     wave_sync();
     BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0, false, {0, 0, 0}};
     bool serial_all = false;
-    SubvoxelWalk sw = {0, 0, 0, 0, 0, 0};
-    CullBox cb0 = {};
     /* ---- stage 1: owners enumerate their cells */
     if (act) {
       iter_idx++;
       STAT_LANE(0);
       STAT_WAVE(0);
-      const double ex = __builtin_fma(step.x, step_l, r0.x);
-      const double ey = __builtin_fma(step.y, step_l, r0.y);
-      const double ez = __builtin_fma(step.z, step_l, r0.z);
-      axis_range(memo, 0, xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex, sw.llx, sw.ulx);
-      axis_range(memo, 1, ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey, sw.lly, sw.uly);
-      axis_range(memo, 2, zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez, sw.llz, sw.ulz);
-      cb0 = make_cull_box(r0, step, step_l);
+      SubvoxelWalk sw;
+      CullBox cb0;
+      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
       const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
       serial_all = nsub > 256;
       if (serial_all) {
@@ -403,6 +372,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         best.d = DS_INF;
         best.visit = 0x7fffffff;
         best.pos = 0x7fffffff;
+        SubvoxelWalk sw; /* recomputed rather than kept in registers through the drain stages */
+        CullBox cb0;
+        segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
         enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       } else {
         const unsigned long long bd = W->best_d[lane];
