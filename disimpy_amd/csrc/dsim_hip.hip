@@ -837,12 +837,19 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
   p.tile_steps = tile;
   const int coop = geom == GEOM_MESH && h->mesh_traversal != 1;
-  if (coop) tile = std::min(tile, std::max(1, 4096 / (mb * 32))); /* leave the LDS to the wave queues */
-  p.tile_steps = tile;
-  int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
-  size_t lds = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1) + (size_t)tile * mb * 4) * sizeof(double);
   const int block = h->block_size;
-  if (coop) lds += (size_t)(block / 64) * sizeof(CoopWave);
+  int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
+  const size_t lds_fixed = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1)) * sizeof(double) +
+                           (coop ? (size_t)(block / 64) * sizeof(CoopWave) : 0);
+  if (coop) {
+    /* two workgroups per CU (2 x 80 KB of the 160 KB LDS): the gradient tile gets what the wave
+     * queues leave, at most 4 KB */
+    const size_t half = 80 * 1024;
+    const size_t room = lds_fixed < half ? half - lds_fixed : 0;
+    tile = std::min(tile, std::max(1, (int)(std::min<size_t>(room, 4096) / ((size_t)mb * 32))));
+  }
+  p.tile_steps = tile;
+  size_t lds = lds_fixed + (size_t)tile * mb * 4 * sizeof(double);
   if (lds > (coop ? 160u : 64u) * 1024u) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int grid = grid_for(h->n, block);
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
