@@ -211,42 +211,6 @@ DSD int ul_subvoxel_overlap(const double *xs, int n, double inv_h, double xmax) 
   return i;
 }
 
-/* The same lookups without touching LDS.  np.linspace(0, L, n + 1) is computed as
- * arange(n + 1) * (L / n) with the last element overwritten by L (numpy/core/function_base.py),
- * so boundary i is exactly fl(i * h) with h = xs[1] for i < n and L for i = n; the host verifies
- * this for the arrays it was given (MeshDev.linear) before the kernels rely on it.  A lookup is
- * then a handful of fp64 operations instead of a chain of dependent LDS reads. */
-struct Axis {
-  const double *xs; /* LDS copy (used when !linear) */
-  int n;
-  double inv_h, inv_l; /* first guesses only */
-  double h, L;         /* xs[1], xs[n] */
-  int linear;
-};
-
-DSD double axis_bound(const Axis &a, int i) { return a.linear ? (i >= a.n ? a.L : (double)i * a.h) : a.xs[i]; }
-
-DSD int ll_subvoxel_overlap(const Axis &a, double xmin) {
-  if (xmin <= axis_bound(a, 0)) return 0;
-  if (xmin >= a.L) return a.n;
-  int i = (int)(xmin * a.inv_h);
-  i = i < 0 ? 0 : (i > a.n - 1 ? a.n - 1 : i);
-  while (axis_bound(a, i) > xmin) --i;
-  while (axis_bound(a, i + 1) <= xmin) ++i;
-  return i;
-}
-
-DSD int ul_subvoxel_overlap(const Axis &a, double xmax) {
-  if (xmax != xmax) return 0;
-  if (xmax >= a.L) return a.n;
-  if (xmax <= axis_bound(a, 0)) return 0;
-  int i = (int)(xmax * a.inv_h) + 1;
-  i = i < 1 ? 1 : (i > a.n ? a.n : i);
-  while (axis_bound(a, i - 1) >= xmax) --i;
-  while (axis_bound(a, i) < xmax) ++i;
-  return i;
-}
-
 /* floor(x / voxel) with the IEEE quotient of the reference (simulations.py:661,
  * :675) but without paying an fp64 division on the common paths:
  *  - 0 <= x < voxel: the correctly rounded quotient is in [0, 1), floor is 0;
@@ -277,22 +241,6 @@ DSD int ul_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, doub
   double k = floor_quotient(xmax, voxel, inv_voxel);
   double shifted = __builtin_fma(-k, voxel, xmax);
   return ul_subvoxel_overlap(xs, n, inv_h, shifted) + (int)k * n;
-}
-
-DSD int ll_subvoxel_overlap_periodic(const Axis &a, double x1, double x2) {
-  double xmin = x1 < x2 ? x1 : x2;
-  double voxel = __builtin_fabs(a.L - axis_bound(a, 0));
-  double k = floor_quotient(xmin, voxel, a.inv_l);
-  double shifted = __builtin_fma(-k, voxel, xmin);
-  return ll_subvoxel_overlap(a, shifted) + (int)k * a.n;
-}
-
-DSD int ul_subvoxel_overlap_periodic(const Axis &a, double x1, double x2) {
-  double xmax = x1 > x2 ? x1 : x2;
-  double voxel = __builtin_fabs(a.L - axis_bound(a, 0));
-  double k = floor_quotient(xmax, voxel, a.inv_l);
-  double shifted = __builtin_fma(-k, voxel, xmax);
-  return ul_subvoxel_overlap(a, shifted) + (int)k * a.n;
 }
 
 /* floor division for the periodic image index (Python: math.floor(x / n)) */

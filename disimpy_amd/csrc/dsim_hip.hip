@@ -203,8 +203,7 @@ struct DevMesh {
   int2 *sv_micro = nullptr, *cell_range = nullptr;
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
-  double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0}, h1[3] = {0, 0, 0};
-  int linear = 0;
+  double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
   bool set = false;
 };
 
@@ -662,13 +661,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     double L = b3[k][n_sv[k]] - b3[k][0];
     dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
     dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
-    dm.h1[k] = b3[k][1];
   }
-  /* boundaries as numpy's linspace(0, L, n + 1) produces them: xs[i] == fl(i * xs[1]) for i < n */
-  dm.linear = 1;
-  for (int k = 0; k < 3; k++)
-    for (int64_t i = 0; i < n_sv[k]; i++)
-      if (b3[k][i] != (double)i * b3[k][1]) dm.linear = 0;
   dm.set = true;
   return DSIM_OK;
 }
@@ -692,10 +685,6 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.inv_lx = dm.inv_l[0];
   m.inv_ly = dm.inv_l[1];
   m.inv_lz = dm.inv_l[2];
-  m.hx = dm.h1[0];
-  m.hy = dm.h1[1];
-  m.hz = dm.h1[2];
-  m.linear = dm.linear;
   return m;
 }
 

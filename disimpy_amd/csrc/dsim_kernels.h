@@ -61,21 +61,7 @@ struct MeshDev {
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
   double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
-  double hx, hy, hz;             /* xs[1], ys[1], zs[1]                   */
-  int linear;                    /* every boundary i < n equals fl(i * h): lookups need no LDS */
 };
-
-DSD Axis mesh_axis(const MeshDev &ms, int k, const double *b) {
-  Axis a;
-  a.xs = b;
-  a.n = k == 0 ? ms.nx : (k == 1 ? ms.ny : ms.nz);
-  a.inv_h = k == 0 ? ms.inv_hx : (k == 1 ? ms.inv_hy : ms.inv_hz);
-  a.inv_l = k == 0 ? ms.inv_lx : (k == 1 ? ms.inv_ly : ms.inv_lz);
-  a.h = k == 0 ? ms.hx : (k == 1 ? ms.hy : ms.hz);
-  a.L = b[a.n];
-  a.linear = ms.linear;
-  return a;
-}
 
 struct WalkParams {
   int64_t n;
@@ -271,7 +257,6 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
   const MeshDev &ms = p.mesh;
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
-  const Axis ax = mesh_axis(ms, 0, xs), ay = mesh_axis(ms, 1, ys), az = mesh_axis(ms, 2, zs);
   int64_t iter_idx = 0;
   bool check = true;
   int closest = 0;
@@ -283,12 +268,12 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
     double ex = __builtin_fma(step.x, step_l, r0.x);
     double ey = __builtin_fma(step.y, step_l, r0.y);
     double ez = __builtin_fma(step.z, step_l, r0.z);
-    int llx = ll_subvoxel_overlap_periodic(ax, r0.x, ex);
-    int lly = ll_subvoxel_overlap_periodic(ay, r0.y, ey);
-    int llz = ll_subvoxel_overlap_periodic(az, r0.z, ez);
-    int ulx = ul_subvoxel_overlap_periodic(ax, r0.x, ex);
-    int uly = ul_subvoxel_overlap_periodic(ay, r0.y, ey);
-    int ulz = ul_subvoxel_overlap_periodic(az, r0.z, ez);
+    int llx = ll_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+    int lly = ll_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+    int llz = ll_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+    int ulx = ul_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+    int uly = ul_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+    int ulz = ul_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
     for (int xi = llx; xi < ulx; xi++) {
       int x = xi;
       double shx = 0;

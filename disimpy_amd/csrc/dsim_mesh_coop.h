@@ -221,13 +221,12 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
   const double ex = __builtin_fma(step.x, step_l, r0.x);
   const double ey = __builtin_fma(step.y, step_l, r0.y);
   const double ez = __builtin_fma(step.z, step_l, r0.z);
-  const Axis ax = mesh_axis(ms, 0, xs), ay = mesh_axis(ms, 1, ys), az = mesh_axis(ms, 2, zs);
-  sw.llx = ll_subvoxel_overlap_periodic(ax, r0.x, ex);
-  sw.lly = ll_subvoxel_overlap_periodic(ay, r0.y, ey);
-  sw.llz = ll_subvoxel_overlap_periodic(az, r0.z, ez);
-  sw.ulx = ul_subvoxel_overlap_periodic(ax, r0.x, ex);
-  sw.uly = ul_subvoxel_overlap_periodic(ay, r0.y, ey);
-  sw.ulz = ul_subvoxel_overlap_periodic(az, r0.z, ez);
+  sw.llx = ll_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+  sw.lly = ll_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+  sw.llz = ll_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+  sw.ulx = ul_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+  sw.uly = ul_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+  sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
   cb0 = make_cull_box(r0, step, step_l);
 }
 
