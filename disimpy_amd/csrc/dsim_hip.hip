@@ -937,6 +937,16 @@ extern "C" int dsim_debug_stats(unsigned long long *out32) {
 }
 #endif
 
+#ifdef DSIM_TIMERS
+/* development build only: read and clear the phase timers of the cooperative traversal */
+extern "C" int dsim_debug_timers(unsigned long long *out16) {
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(dsim_timers), 16 * sizeof(unsigned long long)));
+  unsigned long long zero[16] = {0};
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dsim_timers), zero, sizeof(zero)));
+  return DSIM_OK;
+}
+#endif
+
 extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_ms;

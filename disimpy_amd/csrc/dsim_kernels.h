@@ -34,6 +34,22 @@ __device__ unsigned long long dsim_stats[32];
 #define STAT_WAVE(i)
 #endif
 
+/* Development build (-DDSIM_TIMERS, tools/mesh_timers.py): shader-clock time per phase of the
+ * cooperative traversal, accumulated per wavefront in LDS by lane 0 (T_MARK closes phase i). */
+#ifdef DSIM_TIMERS
+__device__ unsigned long long dsim_timers[16];
+#define T_MARK(W, lane, i)                                        \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_readcyclecounter();   \
+    if ((lane) == 0) {                                            \
+      (W)->tacc[i] += t_ - (W)->tlast;                            \
+      (W)->tlast = t_;                                            \
+    }                                                             \
+  } while (0)
+#else
+#define T_MARK(W, lane, i)
+#endif
+
 /* Timing-ablation switch (-DDSIM_ABLATE, tools/ablate_coop.py; results become wrong, only the
  * timing is of interest): 1 = every subvoxel looks empty, 2 = cells are enumerated but nothing
  * is queued or scanned, 3 = items are culled but survivors are dropped. */
@@ -415,6 +431,12 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
        * reflects needs further passes for the same step while its neighbours already start the
        * next one.  Per walker the sequence of operations (RNG draws included) is unchanged. */
       const int lane = (int)(threadIdx.x & 63);
+#ifdef DSIM_TIMERS
+      if (lane == 0) {
+        for (int q = 0; q < 16; q++) coop->tacc[q] = 0;
+        coop->tlast = __builtin_readcyclecounter();
+      }
+#endif
       int k_lane = 0;
       bool in_step = false;
       V3 step = {0, 0, 0};
@@ -429,6 +451,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
           iter_idx = 0;
           in_step = true;
         }
+        T_MARK(coop, lane, 0);
         const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, p, xs, ys, zs, rng, coop, lane);
         if (in_step && finished) {
           if (iter_idx >= p.max_iter) exc = true; /* simulations.py:999-1002 */
@@ -455,7 +478,12 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
           k_lane++;
           in_step = false;
         }
+        T_MARK(coop, lane, 9);
       }
+#ifdef DSIM_TIMERS
+      if (lane == 0)
+        for (int q = 0; q < 16; q++) atomicAdd(&dsim_timers[q], coop->tacc[q]);
+#endif
     } else if (live) {
       for (int k = 0; k < kt; k++) {
         V3 step = random_step(rng, log_tab, cos_tab);

@@ -30,21 +30,42 @@
 
 #define COOP_ITEM_CAP 512
 #define COOP_SURV_CAP 192
+#define COOP_SVQ_CAP 128
+#define COOP_CELLQ_CAP 256
 
+/* Per-wavefront scratch in LDS.  Two byte pools are reused along the pass:
+ *   pool_a: item queue (stage 1c -> 2), afterwards the survivors' distances and the winners' normals (stage 3);
+ *   pool_b: subvoxel and cell task queues (stage 1a -> 1c), afterwards the survivor pool (stage 2 -> 3). */
 struct CoopWave {
   float box[64][13];                    /* owner's cull box: lo xyz, hi xyz, a xyz, e xyz, tau      3.3 KB */
   double ray[64][6];                    /* owner's r0 xyz, step xyz (fp64, for the exact test)      3.0 KB */
   unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)  0.5 KB */
   unsigned long long best_key[64];      /* (visit << 32) | list position of the winner              0.5 KB */
   int best_tri[64];                     /* its triangle                                                    */
-  double best_n[64][3];                 /* E1 x E2 of that triangle (un-normalised normal)          1.5 KB */
-  int overflow[64];                     /* a survivor of this owner did not fit the pool                   */
-  uint2 items[COOP_ITEM_CAP];           /* {first record | (count-1) << 30, owner|visit|shifts}     2.5 KB */
-  uint4 surv[COOP_SURV_CAP];            /* {triangle, list position, owner|visit|shifts, 0}         4.0 KB */
-  double surv_d[COOP_SURV_CAP];         /* its distance, kept between the reduction passes          2.0 KB */
-  int n_items, n_surv;
-  int pad[2];
+  int overflow[64];                     /* some work of this owner did not fit a queue: redo serially      */
+  unsigned long long pool_a[COOP_ITEM_CAP];                   /*                                    4.0 KB */
+  unsigned long long pool_b[COOP_SURV_CAP * 2];               /*                                    3.0 KB */
+  int n_items, n_surv, n_svq, n_cellq;
+#ifdef DSIM_TIMERS
+  unsigned long long tacc[16], tlast;
+  unsigned long long tpad;
+#endif
 };
+static_assert(COOP_SURV_CAP * 8 + 64 * 3 * 8 <= COOP_ITEM_CAP * 8, "pool_a: distances + normals");
+static_assert((COOP_SVQ_CAP + COOP_CELLQ_CAP) * 8 <= COOP_SURV_CAP * 16, "pool_b: task queues");
+
+/* {first record | (count-1) << 30, owner|visit|shifts} */
+DSD uint2 *coop_items(CoopWave *W) { return reinterpret_cast<uint2 *>(W->pool_a); }
+/* survivor's distance, kept between the reduction passes */
+DSD double *coop_surv_d(CoopWave *W) { return reinterpret_cast<double *>(W->pool_a); }
+/* E1 x E2 of each owner's winning triangle (un-normalised normal), [64][3] */
+DSD double *coop_best_n(CoopWave *W) { return reinterpret_cast<double *>(W->pool_a) + COOP_SURV_CAP; }
+/* {triangle, list position, owner|visit|shifts, 0} */
+DSD uint4 *coop_surv(CoopWave *W) { return reinterpret_cast<uint4 *>(W->pool_b); }
+/* {owner|visit|shifts, x | y << 10 | z << 20} of a subvoxel in range */
+DSD uint2 *coop_svq(CoopWave *W) { return reinterpret_cast<uint2 *>(W->pool_b); }
+/* {owner|visit|shifts, index into cell_range  or  0x80000000 | subvoxel (range stored inline)} */
+DSD uint2 *coop_cellq(CoopWave *W) { return reinterpret_cast<uint2 *>(W->pool_b) + COOP_SVQ_CAP; }
 
 DSD void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -116,48 +137,13 @@ DSD void scan_cell_serial(const MeshDev &ms, int begin, int end, const CullBox &
   }
 }
 
-/* One micro-cell [cr.x, cr.y) of records: queue it as 4-record items for the wavefront, or -
- * when it cannot be queued - let the owner scan it now. */
-template <int MODE>
-DSD void emit_cell(const MeshDev &ms, int2 cr, bool queueable, unsigned tag, const CullBox &cb, const V3 &tr0, const V3 &step,
-                   int visit, CoopWave *W, BestHit &best) {
-  const int cnt = cr.y - cr.x;
-  if (ABLATE(2)) return;
-  bool queued = false;
-  if (MODE == 0 && queueable) {
-    const int nb = (cnt + 3) >> 2;
-    const int base = atomicAdd(&W->n_items, nb);
-    if (base + nb <= COOP_ITEM_CAP) {
-      for (int j = 0; j < nb; j++) {
-        const int left = cnt - 4 * j;
-        W->items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), tag);
-      }
-      queued = true;
-    } else {
-      /* queue full: neutralise the part of the reservation that lies inside the queue */
-      for (int j = base; j < COOP_ITEM_CAP && j < base + nb; j++) W->items[j] = make_uint2(0xffffffffu, 0u);
-    }
-  }
-  if (!queued) {
-    STAT_LANE(8); /* cell scanned serially by its owner */
-    STAT_WAVE(8);
-    scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, visit, best);
-  } else {
-    STAT_LANE(3);
-    STAT_WAVE(3);
-  }
-}
-
 struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
   int llx, lly, llz, ulx, uly, ulz;
 };
 
-/* Enumerate the subvoxels of the iteration in the reference's order.  MODE 0: owner
- * pushes work items (falling back to serial scans when an item cannot be queued);
- * MODE 1: everything serial. */
-template <int MODE>
-DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox &cb0, const V3 &r0, const V3 &step,
-                         const double *xs, const double *ys, const double *zs, CoopWave *W, int lane, BestHit &best) {
+/* The whole iteration of one walker done by its own lane, in the reference's order (fallback). */
+DSD void enumerate_cells_serial(const MeshDev &ms, const SubvoxelWalk &w, const CullBox &cb0, const V3 &r0, const V3 &step,
+                                const double *xs, const double *ys, const double *zs, BestHit &best) {
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
   int visit = 0;
@@ -184,17 +170,14 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
         const double shz = (double)snz * Lz;
         const int v = visit++;
         const int sv = (x * ny + y) * nz + z;
-        STAT_LANE(1);
-        STAT_WAVE(1);
         const int2 mg = ms.sv_micro[sv];
-        if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel */
+        if (mg.x == 0) continue; /* empty subvoxel */
+        STAT_LANE(8); /* subvoxel scanned serially by its owner */
+        STAT_WAVE(8);
         const CullBox cb = shift_cull_box(cb0, shx, shy, shz);
         const V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
-        const bool queueable = MODE == 0 && v < 256 && snx >= -32 && snx < 32 && sny >= -32 && sny < 32 && snz >= -32 && snz < 32;
-        const unsigned tag = (unsigned)lane | ((unsigned)v << 6) | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20) |
-                             ((unsigned)(snz + 32) << 26);
         if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline */
-          emit_cell<MODE>(ms, make_int2(-mg.x - 1, -mg.x - 1 + mg.y), queueable, tag, cb, tr0, step, v, W, best);
+          scan_cell_serial(ms, -mg.x - 1, -mg.x - 1 + mg.y, cb, tr0, step, v, best);
           continue;
         }
         const int k = 1 << mg.y;
@@ -202,17 +185,59 @@ DSD void enumerate_cells(const MeshDev &ms, const SubvoxelWalk &w, const CullBox
         const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
         const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
         const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
-        {
-          for (int a = a0; a <= a1; a++)
-            for (int b = b0; b <= b1; b++)
-              for (int c = c0; c <= c1; c++) {
-                const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
-                if (cr.y > cr.x) emit_cell<MODE>(ms, cr, queueable, tag, cb, tr0, step, v, W, best);
-              }
-        }
+        for (int a = a0; a <= a1; a++)
+          for (int b = b0; b <= b1; b++)
+            for (int c = c0; c <= c1; c++) {
+              const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
+              scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, v, best);
+            }
       }
     }
   }
+}
+
+/* Stage 1a: the owner lists the subvoxels of its iteration (reference order = visit number) as
+ * tasks for the wavefront.  Returns false when they cannot be encoded or queued (the caller
+ * then does the iteration serially). */
+DSD bool push_subvoxels(const MeshDev &ms, const SubvoxelWalk &w, int nsub, CoopWave *W, int lane) {
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  if (nx > 1024 || ny > 1024 || nz > 1024) return false;
+  /* image shifts must fit 6 bits each */
+  if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return false;
+  const int base = atomicAdd(&W->n_svq, nsub);
+  uint2 *q = coop_svq(W);
+  if (base + nsub > COOP_SVQ_CAP) {
+    /* queue full: neutralise the part of the reservation that lies inside the queue */
+    for (int j = base; j < COOP_SVQ_CAP; j++) q[j] = make_uint2(0xffffffffu, 0u);
+    return false;
+  }
+  int j = base;
+  unsigned visit = 0;
+  for (int xi = w.llx; xi < w.ulx; xi++) {
+    int x = xi, snx = 0;
+    if (x < 0 || x > nx - 1) {
+      snx = floor_div(x, nx);
+      x -= snx * nx;
+    }
+    for (int yi = w.lly; yi < w.uly; yi++) {
+      int y = yi, sny = 0;
+      if (y < 0 || y > ny - 1) {
+        sny = floor_div(y, ny);
+        y -= sny * ny;
+      }
+      const unsigned tag_xy = (unsigned)lane | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20);
+      const unsigned cell_xy = (unsigned)x | ((unsigned)y << 10);
+      for (int zi = w.llz; zi < w.ulz; zi++) {
+        int z = zi, snz = 0;
+        if (z < 0 || z > nz - 1) {
+          snz = floor_div(z, nz);
+          z -= snz * nz;
+        }
+        q[j++] = make_uint2(tag_xy | (visit++ << 6) | ((unsigned)(snz + 32) << 26), cell_xy | ((unsigned)z << 20));
+      }
+    }
+  }
+  return true;
 }
 
 /* subvoxel ranges (simulations.py:929-934) and cull box of the remaining segment */
@@ -250,14 +275,20 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     if (lane == 0) {
       W->n_items = 0;
       W->n_surv = 0;
+      W->n_svq = 0;
+      W->n_cellq = 0;
     }
     W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
     W->best_key[lane] = ~0ULL;
     W->overflow[lane] = 0;
     wave_sync();
+    T_MARK(W, lane, 1);
+#ifdef DSIM_TIMERS
+    if (lane == 0) W->tacc[10] += 1;
+#endif
     BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0, false, {0, 0, 0}};
     bool serial_all = false;
-    /* ---- stage 1: owners enumerate their cells */
+    /* ---- stage 1a: owners publish their cull box, ray and subvoxels in range */
     if (act) {
       iter_idx++;
       STAT_LANE(0);
@@ -266,21 +297,99 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       CullBox cb0;
       segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
       const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
-      serial_all = nsub > 256;
+      serial_all = nsub > 256 || !push_subvoxels(ms, sw, (int)nsub, W, lane);
       if (serial_all) {
         STAT_LANE(10);
         STAT_WAVE(10);
-        enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
+        enumerate_cells_serial(ms, sw, cb0, r0, step, xs, ys, zs, best);
       } else {
         float *bx = W->box[lane];
         bx[0] = cb0.lox, bx[1] = cb0.loy, bx[2] = cb0.loz, bx[3] = cb0.hix, bx[4] = cb0.hiy, bx[5] = cb0.hiz;
         bx[6] = cb0.ax, bx[7] = cb0.ay, bx[8] = cb0.az, bx[9] = cb0.ex, bx[10] = cb0.ey, bx[11] = cb0.ez, bx[12] = cb0.tau;
         double *ry = W->ray[lane];
         ry[0] = r0.x, ry[1] = r0.y, ry[2] = r0.z, ry[3] = step.x, ry[4] = step.y, ry[5] = step.z;
-        enumerate_cells<0>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
       }
     }
+    T_MARK(W, lane, 2);
     wave_sync();
+    /* ---- stage 1b: all lanes look the subvoxels up and list the micro-cells the cull box reaches */
+    {
+      const int n = min(W->n_svq, COOP_SVQ_CAP);
+      const uint2 *svq = coop_svq(W);
+      uint2 *cq = coop_cellq(W);
+      for (int idx = lane; idx < n; idx += 64) {
+        const uint2 e = svq[idx];
+        if (e.x == 0xffffffffu) continue;
+        const int x = (int)(e.y & 1023u), y = (int)((e.y >> 10) & 1023u), z = (int)(e.y >> 20);
+        const int sv = (x * ny + y) * nz + z;
+        STAT_LANE(1);
+        STAT_WAVE(1);
+        const int2 mg = ms.sv_micro[sv];
+        if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel */
+        const int owner = (int)(e.x & 63u);
+        int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
+        if (mg.x > 0) {
+          const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
+          const float *bx = W->box[owner];
+          CullBox cb = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+          k = 1 << mg.y;
+          const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
+          a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
+          b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
+          c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+        }
+        const int ncell = (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1);
+        const int base = atomicAdd(&W->n_cellq, ncell);
+        if (base + ncell > COOP_CELLQ_CAP) {
+          for (int j = base; j < COOP_CELLQ_CAP; j++) cq[j] = make_uint2(0xffffffffu, 0u);
+          W->overflow[owner] = 1;
+          continue;
+        }
+        if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline in sv_micro */
+          cq[base] = make_uint2(e.x, 0x80000000u | (unsigned)sv);
+          continue;
+        }
+        int j = base;
+        for (int a = a0; a <= a1; a++)
+          for (int b = b0; b <= b1; b++)
+            for (int c = c0; c <= c1; c++) cq[j++] = make_uint2(e.x, (unsigned)(mg.x + (a * k + b) * k + c));
+      }
+    }
+    T_MARK(W, lane, 12);
+    wave_sync();
+    /* ---- stage 1c: all lanes look the cells up and cut their record ranges into 4-record items */
+    {
+      const int n = min(W->n_cellq, COOP_CELLQ_CAP);
+      const uint2 *cq = coop_cellq(W);
+      uint2 *items = coop_items(W);
+      for (int idx = lane; idx < n; idx += 64) {
+        const uint2 e = cq[idx];
+        if (e.x == 0xffffffffu) continue;
+        const bool inl = (e.y & 0x80000000u) != 0;
+        const int2 *src = inl ? ms.sv_micro + (e.y & 0x7fffffffu) : ms.cell_range + e.y;
+        int2 cr = *src;
+        if (inl) cr = make_int2(-cr.x - 1, -cr.x - 1 + cr.y);
+        const int cnt = cr.y - cr.x;
+        if (cnt <= 0 || ABLATE(2)) continue;
+        STAT_LANE(3);
+        STAT_WAVE(3);
+        const int nb = (cnt + 3) >> 2;
+        const int base = atomicAdd(&W->n_items, nb);
+        if (base + nb > COOP_ITEM_CAP) {
+          for (int j = base; j < COOP_ITEM_CAP; j++) items[j] = make_uint2(0xffffffffu, 0u);
+          W->overflow[(int)(e.x & 63u)] = 1;
+          continue;
+        }
+        for (int j = 0; j < nb; j++) {
+          const int left = cnt - 4 * j;
+          items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), e.x);
+        }
+      }
+    }
+    T_MARK(W, lane, 13);
+    wave_sync();
+    T_MARK(W, lane, 3);
     /* ---- stage 2: all lanes drain the item queue (skipped by wavefronts in open space) */
     const int n_queued = W->n_items;
     if (n_queued > 0) {
@@ -288,7 +397,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       for (int idx = lane; idx < n; idx += 64) {
         STAT_LANE(4);
         STAT_WAVE(4);
-        const uint2 it = W->items[idx];
+        const uint2 it = coop_items(W)[idx];
         if (it.x == 0xffffffffu) continue;
         const int first = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
         const int owner = (int)(it.y & 63u);
@@ -311,7 +420,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb) && !ABLATE(3)) {
             const int slot = atomicAdd(&W->n_surv, 1);
             if (slot < COOP_SURV_CAP)
-              W->surv[slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
+              coop_surv(W)[slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
             else
               W->overflow[owner] = 1;
           }
@@ -319,6 +428,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       }
     }
     if (n_queued > 0) wave_sync();
+    T_MARK(W, lane, 4);
     /* ---- stage 3: all lanes drain the survivor pool (fp64 tests), minimum per owner */
     const int n_surviving = n_queued > 0 ? W->n_surv : 0;
     if (n_surviving > 0) {
@@ -326,7 +436,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       for (int idx = lane; idx < n; idx += 64) { /* pass A: distances, atomic minimum of d */
         STAT_LANE(6);
         STAT_WAVE(6);
-        const uint4 sv = W->surv[idx];
+        const uint4 sv = coop_surv(W)[idx];
         const int owner = (int)(sv.z & 63u);
         const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
         const double *ry = W->ray[owner];
@@ -334,22 +444,23 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const V3 st = {ry[3], ry[4], ry[5]};
         const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
         const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
-        W->surv_d[idx] = d;
+        coop_surv_d(W)[idx] = d;
         if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
       }
       wave_sync();
+      T_MARK(W, lane, 5);
       for (int idx = lane; idx < n; idx += 64) { /* pass B: among equal d the earliest (visit, position) */
-        const uint4 sv = W->surv[idx];
+        const uint4 sv = coop_surv(W)[idx];
         const int owner = (int)(sv.z & 63u);
-        const double d = W->surv_d[idx];
+        const double d = coop_surv_d(W)[idx];
         if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner])
           atomicMin(&W->best_key[owner], ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y);
       }
       wave_sync();
       for (int idx = lane; idx < n; idx += 64) { /* pass C: the winner publishes its triangle */
-        const uint4 sv = W->surv[idx];
+        const uint4 sv = coop_surv(W)[idx];
         const int owner = (int)(sv.z & 63u);
-        const double d = W->surv_d[idx];
+        const double d = coop_surv_d(W)[idx];
         if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
             ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner]) {
           W->best_tri[owner] = (int)sv.x;
@@ -357,12 +468,12 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
            * have to fetch the triangle again before it can reflect */
           const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
           const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
-          W->best_n[owner][0] = nn.x;
-          W->best_n[owner][1] = nn.y;
-          W->best_n[owner][2] = nn.z;
+          double *bn = coop_best_n(W) + 3 * owner;
+          bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
         }
       }
       wave_sync();
+      T_MARK(W, lane, 6);
     }
     if (act && !serial_all) {
       if (W->overflow[lane]) {
@@ -375,7 +486,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         SubvoxelWalk sw; /* recomputed rather than kept in registers through the drain stages */
         CullBox cb0;
         segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
-        enumerate_cells<1>(ms, sw, cb0, r0, step, xs, ys, zs, W, lane, best);
+        enumerate_cells_serial(ms, sw, cb0, r0, step, xs, ys, zs, best);
       } else {
         const unsigned long long bd = W->best_d[lane];
         if (bd != 0x7ff0000000000000ULL) {
@@ -385,13 +496,13 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           offer_hit(best, d_pool, v_pool, p_pool, W->best_tri[lane]);
           if (best.d == d_pool && best.visit == v_pool && best.pos == p_pool) { /* the pool's winner is the overall winner */
             best.have_n = true;
-            best.n.x = W->best_n[lane][0];
-            best.n.y = W->best_n[lane][1];
-            best.n.z = W->best_n[lane][2];
+            const double *bn = coop_best_n(W) + 3 * lane;
+            best.n.x = bn[0], best.n.y = bn[1], best.n.z = bn[2];
           }
         }
       }
     }
+    T_MARK(W, lane, 7);
     /* ---- stage 4: resolve (simulations.py:986-997) */
     if (act) {
       if (best.d > step_l) {
@@ -412,6 +523,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         if (!(step_l > 0 && iter_idx < p.max_iter)) finished = true; /* the while-condition of the next pass */
       }
     }
+    T_MARK(W, lane, 8);
   }
   return finished;
 }
