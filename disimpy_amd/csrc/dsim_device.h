@@ -243,6 +243,31 @@ DSD int ul_subvoxel_overlap_periodic(const double *xs, int n, double inv_h, doub
   return ul_subvoxel_overlap(xs, n, inv_h, shifted) + (int)k * n;
 }
 
+/* Both periodic subvoxel limits of one axis for the segment x1 -> x2 without the search
+ * loops: the multiply's guess is checked against the two boundaries around it (read from
+ * LDS independently of each other and of the other axes).  Returns false when a guess
+ * does not satisfy the conditions the reference's scans end on - the caller then uses
+ * ll/ul_subvoxel_overlap_periodic.  lo = xs[0], hi = xs[n]. */
+DSD bool subvoxel_limits_fast(const double *xs, int n, double lo, double hi, double inv_h, double inv_voxel, double x1, double x2,
+                              int &ll, int &ul) {
+  const double xmin = x1 < x2 ? x1 : x2, xmax = x1 > x2 ? x1 : x2;
+  const double voxel = __builtin_fabs(hi - lo);
+  const double kmin = floor_quotient(xmin, voxel, inv_voxel), kmax = floor_quotient(xmax, voxel, inv_voxel);
+  const double smin = __builtin_fma(-kmin, voxel, xmin), smax = __builtin_fma(-kmax, voxel, xmax);
+  const bool in_min = smin > lo && smin < hi, in_max = smax > lo && smax < hi;
+  int gi = in_min ? (int)(smin * inv_h) : 0;
+  gi = gi < 0 ? 0 : (gi > n - 1 ? n - 1 : gi);
+  int gj = in_max ? (int)(smax * inv_h) + 1 : 1;
+  gj = gj < 1 ? 1 : (gj > n ? n : gj);
+  const double a = xs[gi], b = xs[gi + 1], c = xs[gj - 1], d = xs[gj];
+  /* outside (lo, hi): the early returns of ll/ul_subvoxel_overlap; NaN ends in 0 there as well */
+  const int li = in_min ? gi : (smin >= hi ? n : 0);
+  const int ui = in_max ? gj : (smax >= hi ? n : 0);
+  ll = li + (int)kmin * n;
+  ul = ui + (int)kmax * n;
+  return (!in_min || (a <= smin && smin < b)) && (!in_max || (c < smax && smax <= d));
+}
+
 /* floor division for the periodic image index (Python: math.floor(x / n)) */
 DSD int floor_div(int x, int n) {
   int q = x / n;

@@ -204,6 +204,7 @@ struct DevMesh {
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
   double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; /* first and last boundary of every axis */
   bool set = false;
 };
 
@@ -661,6 +662,8 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     double L = b3[k][n_sv[k]] - b3[k][0];
     dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
     dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
+    dm.lo[k] = b3[k][0];
+    dm.hi[k] = b3[k][n_sv[k]];
   }
   dm.set = true;
   return DSIM_OK;
@@ -685,6 +688,8 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.inv_lx = dm.inv_l[0];
   m.inv_ly = dm.inv_l[1];
   m.inv_lz = dm.inv_l[2];
+  m.x0 = dm.lo[0], m.y0 = dm.lo[1], m.z0 = dm.lo[2];
+  m.x1 = dm.hi[0], m.y1 = dm.hi[1], m.z1 = dm.hi[2];
   return m;
 }
 
@@ -842,11 +847,13 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   const size_t lds_fixed = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1)) * sizeof(double) +
                            (coop ? (size_t)(block / 64) * sizeof(CoopWave) : 0);
   if (coop) {
-    /* two workgroups per CU (2 x 80 KB of the 160 KB LDS): the gradient tile gets what the wave
-     * queues leave, at most 4 KB */
-    const size_t half = 80 * 1024;
-    const size_t room = lds_fixed < half ? half - lds_fixed : 0;
-    tile = std::min(tile, std::max(1, (int)(std::min<size_t>(room, 4096) / ((size_t)mb * 32))));
+    /* three workgroups per CU (3 x 53 KB of the 160 KB LDS; the kernel needs < 168 VGPRs): the
+     * gradient tile gets what the wave queues leave; when that is less than 16 time steps, two
+     * workgroups per CU (2 x 80 KB) and a tile of at most 4 KB */
+    const size_t third = 41 * 1280, half = 80 * 1024 /* LDS is allocated in 1280-byte granules */, per_step = (size_t)mb * 32;
+    size_t room = lds_fixed < third ? third - lds_fixed : 0;
+    if (room < 16 * per_step) room = std::min<size_t>(lds_fixed < half ? half - lds_fixed : 0, 4096);
+    tile = std::min(tile, std::max(1, (int)(room / per_step)));
   }
   p.tile_steps = tile;
   size_t lds = lds_fixed + (size_t)tile * mb * 4 * sizeof(double);

@@ -77,6 +77,7 @@ struct MeshDev {
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
   double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
+  double x0, y0, z0, x1, y1, z1; /* xs[0], ys[0], zs[0], xs[nx], ys[ny], zs[nz] */
 };
 
 struct WalkParams {

@@ -28,44 +28,43 @@
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
-#define COOP_ITEM_CAP 512
-#define COOP_SURV_CAP 192
-#define COOP_SVQ_CAP 128
+#define COOP_ITEM_CAP 448
+#define COOP_SURV_CAP 128
+#define COOP_SVQ_CAP 448
 #define COOP_CELLQ_CAP 256
 
-/* Per-wavefront scratch in LDS.  Two byte pools are reused along the pass:
- *   pool_a: item queue (stage 1c -> 2), afterwards the survivors' distances and the winners' normals (stage 3);
- *   pool_b: subvoxel and cell task queues (stage 1a -> 1c), afterwards the survivor pool (stage 2 -> 3). */
+/* Per-wavefront scratch in LDS (10.1 KB: three 256-thread workgroups per CU).  The owners' cull
+ * boxes and rays are NOT here: they stay in the owners' registers and the lane that works on an
+ * item reads them with ds_bpermute (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
-  float box[64][13];                    /* owner's cull box: lo xyz, hi xyz, a xyz, e xyz, tau      3.3 KB */
-  double ray[64][6];                    /* owner's r0 xyz, step xyz (fp64, for the exact test)      3.0 KB */
-  unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)  0.5 KB */
-  unsigned long long best_key[64];      /* (visit << 32) | list position of the winner              0.5 KB */
-  int best_tri[64];                     /* its triangle                                                    */
-  int overflow[64];                     /* some work of this owner did not fit a queue: redo serially      */
-  unsigned long long pool_a[COOP_ITEM_CAP];                   /*                                    4.0 KB */
-  unsigned long long pool_b[COOP_SURV_CAP * 2];               /*                                    3.0 KB */
-  int n_items, n_surv, n_svq, n_cellq;
+  unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)      0.5 KB */
+  unsigned long long best_key[64];      /* (visit << 32) | list position of the winner                  0.5 KB */
+  double best_n[64][3];                 /* E1 x E2 of the winner's triangle (un-normalised normal)      1.5 KB */
+  uint2 items[COOP_ITEM_CAP];           /* subvoxel tasks {owner|visit|shifts, x | y << 10 | z << 20} (stage 1a -> 1b), then
+                                           items {first record | (count-1) << 30, owner|visit|shifts} (1c -> 2)  3.5 KB */
+  uint2 cellq[COOP_CELLQ_CAP];          /* cell tasks {owner|visit|shifts, index into cell_range  or
+                                           0x80000000 | subvoxel (range stored inline)} (1b -> 1c)      2.0 KB */
+  uint4 surv[COOP_SURV_CAP];            /* survivors {triangle, list position, owner|visit|shifts, 0}   2.0 KB */
+  unsigned char overflow[64];           /* some work of this owner did not fit a queue: redo serially          */
+  int n_surv, n_svq, n_cellq, pad;
 #ifdef DSIM_TIMERS
   unsigned long long tacc[16], tlast;
   unsigned long long tpad;
 #endif
 };
-static_assert(COOP_SURV_CAP * 8 + 64 * 3 * 8 <= COOP_ITEM_CAP * 8, "pool_a: distances + normals");
-static_assert((COOP_SVQ_CAP + COOP_CELLQ_CAP) * 8 <= COOP_SURV_CAP * 16, "pool_b: task queues");
+static_assert(COOP_SVQ_CAP <= COOP_ITEM_CAP, "subvoxel tasks share the item queue");
+static_assert(COOP_SURV_CAP <= 128, "stage 3 keeps two distances per lane in registers");
 
-/* {first record | (count-1) << 30, owner|visit|shifts} */
-DSD uint2 *coop_items(CoopWave *W) { return reinterpret_cast<uint2 *>(W->pool_a); }
-/* survivor's distance, kept between the reduction passes */
-DSD double *coop_surv_d(CoopWave *W) { return reinterpret_cast<double *>(W->pool_a); }
-/* E1 x E2 of each owner's winning triangle (un-normalised normal), [64][3] */
-DSD double *coop_best_n(CoopWave *W) { return reinterpret_cast<double *>(W->pool_a) + COOP_SURV_CAP; }
-/* {triangle, list position, owner|visit|shifts, 0} */
-DSD uint4 *coop_surv(CoopWave *W) { return reinterpret_cast<uint4 *>(W->pool_b); }
-/* {owner|visit|shifts, x | y << 10 | z << 20} of a subvoxel in range */
-DSD uint2 *coop_svq(CoopWave *W) { return reinterpret_cast<uint2 *>(W->pool_b); }
-/* {owner|visit|shifts, index into cell_range  or  0x80000000 | subvoxel (range stored inline)} */
-DSD uint2 *coop_cellq(CoopWave *W) { return reinterpret_cast<uint2 *>(W->pool_b) + COOP_SVQ_CAP; }
+DSD uint2 *coop_items(CoopWave *W) { return W->items; }
+DSD uint4 *coop_surv(CoopWave *W) { return W->surv; }
+DSD uint2 *coop_svq(CoopWave *W) { return W->items; }
+DSD uint2 *coop_cellq(CoopWave *W) { return W->cellq; }
+
+DSD double shfl_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl((int)(b & 0xffffffffLL), src, 64), hi = __shfl((int)(b >> 32), src, 64);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
 
 DSD void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -124,26 +123,16 @@ DSD bool cull_record(const float4 &q0, const float4 &q1, const float4 &q2, const
   return (s0 > cb.tau && s1 > cb.tau) || (s0 < -cb.tau && s1 < -cb.tau);
 }
 
-/* serial scan of one micro-cell by its owner (fallback path) */
-DSD void scan_cell_serial(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step, int visit,
-                          BestHit &best) {
-  for (int i = begin; i < end; i++) {
-    const float4 q0 = ms.mrec[3 * i], q1 = ms.mrec[3 * i + 1], q2 = ms.mrec[3 * i + 2];
-    if (cull_record(q0, q1, q2, cb)) continue;
-    const int ti = __float_as_int(q2.z), pos = __float_as_int(q2.w);
-    const double *rec = ms.tri + (int64_t)ti * 9;
-    double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
-    offer_hit(best, d, visit, pos, ti);
-  }
-}
-
 struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
   int llx, lly, llz, ulx, uly, ulz;
 };
 
-/* The whole iteration of one walker done by its own lane, in the reference's order (fallback). */
-DSD void enumerate_cells_serial(const MeshDev &ms, const SubvoxelWalk &w, const CullBox &cb0, const V3 &r0, const V3 &step,
-                                const double *xs, const double *ys, const double *zs, BestHit &best) {
+/* Fallback: the whole iteration of one walker done by its own lane exactly as the reference does
+ * it (simulations.py:936-983): every triangle of every subvoxel in range, no culling.  Kept
+ * deliberately small in registers - the occupancy of the kernel is set by its largest code path
+ * and this one runs only when a walker's work does not fit the wavefront's queues. */
+DSD void iteration_serial(const MeshDev &ms, const SubvoxelWalk &w, const V3 &r0, const V3 &step, const double *xs,
+                          const double *ys, const double *zs, BestHit &best) {
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
   int visit = 0;
@@ -153,44 +142,30 @@ DSD void enumerate_cells_serial(const MeshDev &ms, const SubvoxelWalk &w, const 
       snx = floor_div(x, nx);
       x -= snx * nx;
     }
-    const double shx = (double)snx * Lx;
     for (int yi = w.lly; yi < w.uly; yi++) {
       int y = yi, sny = 0;
       if (y < 0 || y > ny - 1) {
         sny = floor_div(y, ny);
         y -= sny * ny;
       }
-      const double shy = (double)sny * Ly;
       for (int zi = w.llz; zi < w.ulz; zi++) {
         int z = zi, snz = 0;
         if (z < 0 || z > nz - 1) {
           snz = floor_div(z, nz);
           z -= snz * nz;
         }
-        const double shz = (double)snz * Lz;
         const int v = visit++;
-        const int sv = (x * ny + y) * nz + z;
-        const int2 mg = ms.sv_micro[sv];
-        if (mg.x == 0) continue; /* empty subvoxel */
+        const int2 rg = ms.sv_range[(x * ny + y) * nz + z];
+        if (rg.y <= rg.x) continue;
         STAT_LANE(8); /* subvoxel scanned serially by its owner */
         STAT_WAVE(8);
-        const CullBox cb = shift_cull_box(cb0, shx, shy, shz);
-        const V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
-        if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline */
-          scan_cell_serial(ms, -mg.x - 1, -mg.x - 1 + mg.y, cb, tr0, step, v, best);
-          continue;
+        const V3 tr0 = {r0.x - (double)snx * Lx, r0.y - (double)sny * Ly, r0.z - (double)snz * Lz};
+        for (int i = rg.x; i < rg.y; i++) {
+          const int ti = ms.tri_idx[i];
+          const double *rec = ms.tri + (int64_t)ti * 9;
+          const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
+          offer_hit(best, d, v, i, ti);
         }
-        const int k = 1 << mg.y;
-        const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
-        const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
-        const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
-        const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
-        for (int a = a0; a <= a1; a++)
-          for (int b = b0; b <= b1; b++)
-            for (int c = c0; c <= c1; c++) {
-              const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
-              scan_cell_serial(ms, cr.x, cr.y, cb, tr0, step, v, best);
-            }
       }
     }
   }
@@ -211,29 +186,36 @@ DSD bool push_subvoxels(const MeshDev &ms, const SubvoxelWalk &w, int nsub, Coop
     for (int j = base; j < COOP_SVQ_CAP; j++) q[j] = make_uint2(0xffffffffu, 0u);
     return false;
   }
-  int j = base;
-  unsigned visit = 0;
-  for (int xi = w.llx; xi < w.ulx; xi++) {
-    int x = xi, snx = 0;
-    if (x < 0 || x > nx - 1) {
-      snx = floor_div(x, nx);
-      x -= snx * nx;
-    }
-    for (int yi = w.lly; yi < w.uly; yi++) {
-      int y = yi, sny = 0;
-      if (y < 0 || y > ny - 1) {
-        sny = floor_div(y, ny);
-        y -= sny * ny;
-      }
-      const unsigned tag_xy = (unsigned)lane | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20);
-      const unsigned cell_xy = (unsigned)x | ((unsigned)y << 10);
-      for (int zi = w.llz; zi < w.ulz; zi++) {
-        int z = zi, snz = 0;
-        if (z < 0 || z > nz - 1) {
-          snz = floor_div(z, nz);
-          z -= snz * nz;
-        }
-        q[j++] = make_uint2(tag_xy | (visit++ << 6) | ((unsigned)(snz + 32) << 26), cell_xy | ((unsigned)z << 20));
+  /* wrapped index and image number of the first subvoxel on every axis; the loop then steps
+   * through the range z-fastest (simulations.py:936-938) without further divisions */
+  int x = w.llx, snx = 0, y0 = w.lly, sny0 = 0, z0 = w.llz, snz0 = 0;
+  if (x < 0 || x > nx - 1) {
+    snx = floor_div(x, nx);
+    x -= snx * nx;
+  }
+  if (y0 < 0 || y0 > ny - 1) {
+    sny0 = floor_div(y0, ny);
+    y0 -= sny0 * ny;
+  }
+  if (z0 < 0 || z0 > nz - 1) {
+    snz0 = floor_div(z0, nz);
+    z0 -= snz0 * nz;
+  }
+  int y = y0, sny = sny0, z = z0, snz = snz0, yi = w.lly, zi = w.llz;
+  for (unsigned v = 0; v < (unsigned)nsub; v++) {
+    q[base + v] = make_uint2((unsigned)lane | (v << 6) | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20) |
+                                 ((unsigned)(snz + 32) << 26),
+                             (unsigned)x | ((unsigned)y << 10) | ((unsigned)z << 20));
+    zi++, z++;
+    if (z == nz) z = 0, snz++;
+    if (zi == w.ulz) {
+      zi = w.llz, z = z0, snz = snz0;
+      yi++, y++;
+      if (y == ny) y = 0, sny++;
+      if (yi == w.uly) {
+        yi = w.lly, y = y0, sny = sny0;
+        x++;
+        if (x == nx) x = 0, snx++;
       }
     }
   }
@@ -246,13 +228,89 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
   const double ex = __builtin_fma(step.x, step_l, r0.x);
   const double ey = __builtin_fma(step.y, step_l, r0.y);
   const double ez = __builtin_fma(step.z, step_l, r0.z);
+  const bool fx = subvoxel_limits_fast(xs, ms.nx, ms.x0, ms.x1, ms.inv_hx, ms.inv_lx, r0.x, ex, sw.llx, sw.ulx);
+  const bool fy = subvoxel_limits_fast(ys, ms.ny, ms.y0, ms.y1, ms.inv_hy, ms.inv_ly, r0.y, ey, sw.lly, sw.uly);
+  const bool fz = subvoxel_limits_fast(zs, ms.nz, ms.z0, ms.z1, ms.inv_hz, ms.inv_lz, r0.z, ez, sw.llz, sw.ulz);
+  cb0 = make_cull_box(r0, step, step_l);
+  if (fx && fy && fz) return;
   sw.llx = ll_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
   sw.lly = ll_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
   sw.llz = ll_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
   sw.ulx = ul_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
   sw.uly = ul_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
   sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
-  cb0 = make_cull_box(r0, step, step_l);
+}
+
+/* Stage 3: all lanes drain the survivor pool - fp64 Moller-Trumbore test with the owner's ray,
+ * minimum per owner by 64-bit LDS atomics on the bit pattern of d, ties resolved by a second
+ * atomic pass on (visit, list position), the winner publishes its normal.  May run several
+ * times per pass (the pool is flushed whenever it is half full); seen_d is best_d[lane] as of
+ * the previous flush.  Every lane of the wavefront must call this. */
+DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWave *W, int lane, unsigned long long &seen_d) {
+  const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1;
+  const int n_surv = min(W->n_surv, COOP_SURV_CAP);
+  double my_d[2] = {0, 0}; /* n_surv <= 2 * 64: at most two survivors per lane */
+#pragma unroll
+  for (int trip = 0; trip < 2; trip++) { /* pass A: distances, atomic minimum of d */
+    if (trip * 64 >= n_surv) break;
+    const int idx = trip * 64 + lane;
+    const bool valid = idx < n_surv;
+    uint4 sv = make_uint4(0u, 0u, 0u, 0u);
+    if (valid) sv = coop_surv(W)[idx];
+    const int owner = (int)(sv.z & 63u);
+    V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
+    const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
+    if (!valid) continue;
+    STAT_LANE(6);
+    STAT_WAVE(6);
+    const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
+    tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
+    const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+    const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
+    my_d[trip] = d;
+    if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
+  }
+  wave_sync();
+  T_MARK(W, lane, 5);
+  { /* a smaller minimum than at the last flush invalidates the tie-break key of the earlier one */
+    const unsigned long long cur = W->best_d[lane];
+    if (cur != seen_d) {
+      W->best_key[lane] = ~0ULL;
+      seen_d = cur;
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int trip = 0; trip < 2; trip++) { /* pass B: among equal d the earliest (visit, position) */
+    const int idx = trip * 64 + lane;
+    if (idx >= n_surv) continue;
+    const uint4 sv = coop_surv(W)[idx];
+    const int owner = (int)(sv.z & 63u);
+    const double d = my_d[trip];
+    if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner])
+      atomicMin(&W->best_key[owner], ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y);
+  }
+  wave_sync();
+#pragma unroll
+  for (int trip = 0; trip < 2; trip++) { /* pass C: the winner publishes its triangle's normal */
+    const int idx = trip * 64 + lane;
+    if (idx >= n_surv) continue;
+    const uint4 sv = coop_surv(W)[idx];
+    const int owner = (int)(sv.z & 63u);
+    const double d = my_d[trip];
+    if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
+        ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner]) {
+      /* the record is still in the vector L1: publish E1 x E2 so that the owner does not have to
+       * fetch the triangle before it can reflect ((A-B)x(A-C) == E1 x E2 bit for bit) */
+      const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+      const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
+      double *bn = W->best_n[owner];
+      bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
+    }
+  }
+  if (lane == 0) W->n_surv = 0;
+  wave_sync();
+  T_MARK(W, lane, 6);
 }
 
 /* ONE pass of the reflect loop of simulations.py:924-997 for the 64 walkers of a wavefront
@@ -265,152 +323,173 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
 DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, const WalkParams &p, const double *xs,
                         const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
   const MeshDev &ms = p.mesh;
-  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
-  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
+  const int ny = ms.ny, nz = ms.nz;
+  const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1; /* = xs[nx], ys[ny], zs[nz] */
   bool finished = false;
-  {
-    const bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
-    if (in_step && !act) finished = true; /* while-condition false on entry */
-    if (__ballot(act) == 0ULL) return finished;
-    if (lane == 0) {
-      W->n_items = 0;
-      W->n_surv = 0;
-      W->n_svq = 0;
-      W->n_cellq = 0;
-    }
-    W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
-    W->best_key[lane] = ~0ULL;
-    W->overflow[lane] = 0;
-    wave_sync();
-    T_MARK(W, lane, 1);
+  const bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
+  if (in_step && !act) finished = true; /* while-condition false on entry */
+  if (__ballot(act) == 0ULL) return finished;
+  if (lane == 0) {
+    W->n_surv = 0;
+    W->n_svq = 0;
+    W->n_cellq = 0;
+  }
+  W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
+  W->best_key[lane] = ~0ULL;
+  W->overflow[lane] = 0;
+  wave_sync();
+  T_MARK(W, lane, 1);
 #ifdef DSIM_TIMERS
-    if (lane == 0) W->tacc[10] += 1;
+  if (lane == 0) W->tacc[10] += 1;
 #endif
-    BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0, false, {0, 0, 0}};
-    bool serial_all = false;
-    /* ---- stage 1a: owners publish their cull box, ray and subvoxels in range */
-    if (act) {
-      iter_idx++;
-      STAT_LANE(0);
-      STAT_WAVE(0);
-      SubvoxelWalk sw;
-      CullBox cb0;
-      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
-      const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
-      serial_all = nsub > 256 || !push_subvoxels(ms, sw, (int)nsub, W, lane);
-      if (serial_all) {
-        STAT_LANE(10);
-        STAT_WAVE(10);
-        enumerate_cells_serial(ms, sw, cb0, r0, step, xs, ys, zs, best);
-      } else {
-        float *bx = W->box[lane];
-        bx[0] = cb0.lox, bx[1] = cb0.loy, bx[2] = cb0.loz, bx[3] = cb0.hix, bx[4] = cb0.hiy, bx[5] = cb0.hiz;
-        bx[6] = cb0.ax, bx[7] = cb0.ay, bx[8] = cb0.az, bx[9] = cb0.ex, bx[10] = cb0.ey, bx[11] = cb0.ez, bx[12] = cb0.tau;
-        double *ry = W->ray[lane];
-        ry[0] = r0.x, ry[1] = r0.y, ry[2] = r0.z, ry[3] = step.x, ry[4] = step.y, ry[5] = step.z;
-      }
-    }
-    T_MARK(W, lane, 2);
-    wave_sync();
-    /* ---- stage 1b: all lanes look the subvoxels up and list the micro-cells the cull box reaches */
-    {
-      const int n = min(W->n_svq, COOP_SVQ_CAP);
-      const uint2 *svq = coop_svq(W);
-      uint2 *cq = coop_cellq(W);
-      for (int idx = lane; idx < n; idx += 64) {
-        const uint2 e = svq[idx];
-        if (e.x == 0xffffffffu) continue;
-        const int x = (int)(e.y & 1023u), y = (int)((e.y >> 10) & 1023u), z = (int)(e.y >> 20);
-        const int sv = (x * ny + y) * nz + z;
+  bool serial = false;
+  /* ---- stage 1a: owners work out their cull box and list their subvoxels in range.  Box and ray
+   * stay in the owner's registers (cb0, r0, step: unchanged until stage 4); the other lanes read
+   * them with __shfl, so every lane has to be active wherever a shuffle is executed. */
+  CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (act) {
+    iter_idx++;
+    STAT_LANE(0);
+    STAT_WAVE(0);
+    SubvoxelWalk sw;
+    segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
+    const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
+    serial = nsub > 256 || !push_subvoxels(ms, sw, (int)nsub, W, lane);
+  }
+  T_MARK(W, lane, 2);
+  wave_sync();
+  /* ---- stage 1b: all lanes look the subvoxels up and list the micro-cells the cull box reaches */
+  {
+    const int n = min(W->n_svq, COOP_SVQ_CAP);
+    const uint2 *svq = coop_svq(W);
+    uint2 *cq = coop_cellq(W);
+    for (int first = 0; first < n; first += 64) {
+      const int idx = first + lane;
+      uint2 e = make_uint2(0xffffffffu, 0u);
+      if (idx < n) e = svq[idx];
+      const bool valid = e.x != 0xffffffffu;
+      const int owner = (int)(e.x & 63u);
+      const int x = (int)(e.y & 1023u), y = (int)((e.y >> 10) & 1023u), z = (int)(e.y >> 20);
+      const int sv = (x * ny + y) * nz + z;
+      int2 mg = make_int2(0, 0);
+      if (valid) {
         STAT_LANE(1);
         STAT_WAVE(1);
-        const int2 mg = ms.sv_micro[sv];
-        if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel */
-        const int owner = (int)(e.x & 63u);
-        int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
-        if (mg.x > 0) {
-          const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
-          const float *bx = W->box[owner];
-          CullBox cb = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
-          k = 1 << mg.y;
-          const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
-          a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
-          b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
-          c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
-        }
-        const int ncell = (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1);
-        const int base = atomicAdd(&W->n_cellq, ncell);
-        if (base + ncell > COOP_CELLQ_CAP) {
-          for (int j = base; j < COOP_CELLQ_CAP; j++) cq[j] = make_uint2(0xffffffffu, 0u);
-          W->overflow[owner] = 1;
-          continue;
-        }
-        if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline in sv_micro */
-          cq[base] = make_uint2(e.x, 0x80000000u | (unsigned)sv);
-          continue;
-        }
-        int j = base;
-        for (int a = a0; a <= a1; a++)
-          for (int b = b0; b <= b1; b++)
-            for (int c = c0; c <= c1; c++) cq[j++] = make_uint2(e.x, (unsigned)(mg.x + (a * k + b) * k + c));
+        mg = ms.sv_micro[sv];
       }
+      CullBox cb = {__shfl(cb0.lox, owner, 64), __shfl(cb0.loy, owner, 64), __shfl(cb0.loz, owner, 64), __shfl(cb0.hix, owner, 64),
+                    __shfl(cb0.hiy, owner, 64), __shfl(cb0.hiz, owner, 64), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel (or no task for this lane) */
+      int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
+      if (mg.x > 0) {
+        const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
+        cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        k = 1 << mg.y;
+        const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
+        a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
+        b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
+        c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+      }
+      const int ncell = (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1);
+      const int base = atomicAdd(&W->n_cellq, ncell);
+      if (base + ncell > COOP_CELLQ_CAP) {
+        for (int j = base; j < COOP_CELLQ_CAP; j++) cq[j] = make_uint2(0xffffffffu, 0u);
+        W->overflow[owner] = 1;
+        continue;
+      }
+      if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline in sv_micro */
+        cq[base] = make_uint2(e.x, 0x80000000u | (unsigned)sv);
+        continue;
+      }
+      int j = base;
+      for (int a = a0; a <= a1; a++)
+        for (int b = b0; b <= b1; b++)
+          for (int c = c0; c <= c1; c++) cq[j++] = make_uint2(e.x, (unsigned)(mg.x + (a * k + b) * k + c));
     }
-    T_MARK(W, lane, 12);
-    wave_sync();
-    /* ---- stage 1c: all lanes look the cells up and cut their record ranges into 4-record items */
-    {
-      const int n = min(W->n_cellq, COOP_CELLQ_CAP);
-      const uint2 *cq = coop_cellq(W);
-      uint2 *items = coop_items(W);
-      for (int idx = lane; idx < n; idx += 64) {
-        const uint2 e = cq[idx];
-        if (e.x == 0xffffffffu) continue;
-        const bool inl = (e.y & 0x80000000u) != 0;
-        const int2 *src = inl ? ms.sv_micro + (e.y & 0x7fffffffu) : ms.cell_range + e.y;
-        int2 cr = *src;
-        if (inl) cr = make_int2(-cr.x - 1, -cr.x - 1 + cr.y);
-        const int cnt = cr.y - cr.x;
-        if (cnt <= 0 || ABLATE(2)) continue;
-        STAT_LANE(3);
-        STAT_WAVE(3);
+  }
+  T_MARK(W, lane, 12);
+  wave_sync();
+  /* ---- stages 1c, 2, 3 in rounds: the cell tasks are cut into 4-record items until the item queue
+   * is nearly full, the items are drained into the survivor pool, the pool is flushed (fp64 tests,
+   * per-owner minimum) when it is half full - so no queue size limits the amount of work per pass */
+  {
+    const int n_cells = min(W->n_cellq, COOP_CELLQ_CAP);
+    const uint2 *cq = coop_cellq(W);
+    uint2 *items = coop_items(W);
+    unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
+    int cursor = 0;
+    while (cursor < n_cells) {
+      /* -- 1c: up to 64 cell tasks per round, one per lane */
+      int n_items = 0;
+      while (cursor < n_cells && n_items <= COOP_ITEM_CAP - 64) {
+        const int idx = cursor + lane;
+        uint2 e = make_uint2(0xffffffffu, 0u);
+        if (idx < n_cells) e = cq[idx];
+        int2 cr = make_int2(0, 0);
+        if (e.x != 0xffffffffu) {
+          const bool inl = (e.y & 0x80000000u) != 0;
+          const int2 *src = inl ? ms.sv_micro + (e.y & 0x7fffffffu) : ms.cell_range + e.y;
+          cr = *src;
+          if (inl) cr = make_int2(-cr.x - 1, -cr.x - 1 + cr.y);
+        }
+        const int cnt = ABLATE(2) ? 0 : max(0, cr.y - cr.x);
         const int nb = (cnt + 3) >> 2;
-        const int base = atomicAdd(&W->n_items, nb);
-        if (base + nb > COOP_ITEM_CAP) {
-          for (int j = base; j < COOP_ITEM_CAP; j++) items[j] = make_uint2(0xffffffffu, 0u);
-          W->overflow[(int)(e.x & 63u)] = 1;
+        if (nb > 0) {
+          STAT_LANE(3);
+          STAT_WAVE(3);
+        }
+        int incl = nb; /* inclusive prefix sum over the lanes */
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int up = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += up;
+        }
+        const unsigned long long fits = __ballot(n_items + incl <= COOP_ITEM_CAP);
+        const int n_take = fits == ~0ULL ? 64 : (int)__ffsll((long long)~fits) - 1; /* the lanes that fit form a prefix */
+        if (n_take == 0) {
+          if (n_items > 0) break; /* drain first, then retry with an empty queue */
+          /* a single cell with more records than the whole queue holds: its owner works serially */
+          if (lane == 0) W->overflow[(int)(e.x & 63u)] = 1;
+          cursor += 1;
           continue;
         }
-        for (int j = 0; j < nb; j++) {
-          const int left = cnt - 4 * j;
-          items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), e.x);
+        if (lane < n_take) {
+          const int base = n_items + incl - nb;
+          for (int j = 0; j < nb; j++) {
+            const int left = cnt - 4 * j;
+            items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), e.x);
+          }
         }
+        n_items += __shfl(incl, n_take - 1, 64);
+        cursor += n_take;
+        if (n_take < 64) break;
       }
-    }
-    T_MARK(W, lane, 13);
-    wave_sync();
-    T_MARK(W, lane, 3);
-    /* ---- stage 2: all lanes drain the item queue (skipped by wavefronts in open space) */
-    const int n_queued = W->n_items;
-    if (n_queued > 0) {
-      const int n = min(n_queued, COOP_ITEM_CAP);
-      for (int idx = lane; idx < n; idx += 64) {
+      T_MARK(W, lane, 13);
+      if (n_items == 0) continue;
+      wave_sync();
+      /* -- 2: all lanes drain the item queue: float32 AABB + plane culling against the owner's box */
+      for (int first = 0; first < n_items; first += 64) {
+        const int idx = first + lane;
+        const bool valid = idx < n_items;
+        uint2 it = make_uint2(0u, 0u);
+        if (valid) it = items[idx];
+        const int owner = (int)(it.y & 63u);
+        CullBox cb;
+        cb.lox = __shfl(cb0.lox, owner, 64), cb.loy = __shfl(cb0.loy, owner, 64), cb.loz = __shfl(cb0.loz, owner, 64);
+        cb.hix = __shfl(cb0.hix, owner, 64), cb.hiy = __shfl(cb0.hiy, owner, 64), cb.hiz = __shfl(cb0.hiz, owner, 64);
+        cb.ax = __shfl(cb0.ax, owner, 64), cb.ay = __shfl(cb0.ay, owner, 64), cb.az = __shfl(cb0.az, owner, 64);
+        cb.ex = __shfl(cb0.ex, owner, 64), cb.ey = __shfl(cb0.ey, owner, 64), cb.ez = __shfl(cb0.ez, owner, 64);
+        cb.tau = __shfl(cb0.tau, owner, 64);
+        if (valid) {
         STAT_LANE(4);
         STAT_WAVE(4);
-        const uint2 it = coop_items(W)[idx];
-        if (it.x == 0xffffffffu) continue;
-        const int first = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
-        const int owner = (int)(it.y & 63u);
+        const int first_rec = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
         const int snx = (int)((it.y >> 14) & 63u) - 32, sny = (int)((it.y >> 20) & 63u) - 32, snz = (int)(it.y >> 26) - 32;
-        const float *bx = W->box[owner];
-        CullBox cb;
-        cb.lox = bx[0], cb.loy = bx[1], cb.loz = bx[2], cb.hix = bx[3], cb.hiy = bx[4], cb.hiz = bx[5];
-        cb.ax = bx[6], cb.ay = bx[7], cb.az = bx[8], cb.ex = bx[9], cb.ey = bx[10], cb.ez = bx[11], cb.tau = bx[12];
         cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
         float4 q0[4], q1[4], q2[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int j = first + min(u, cnt - 1);
+          const int j = first_rec + min(u, cnt - 1);
           q0[u] = ms.mrec[3 * j];
           q1[u] = ms.mrec[3 * j + 1];
           q2[u] = ms.mrec[3 * j + 2];
@@ -425,106 +504,56 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
               W->overflow[owner] = 1;
           }
         }
+        }
+        T_MARK(W, lane, 4);
+        /* a trip adds 15 survivors on average and 256 at most: flush the pool once it is half full */
+        wave_sync();
+        if (W->n_surv > COOP_SURV_CAP / 2) flush_survivors(ms, r0, step, W, lane, seen_d);
       }
     }
-    if (n_queued > 0) wave_sync();
-    T_MARK(W, lane, 4);
-    /* ---- stage 3: all lanes drain the survivor pool (fp64 tests), minimum per owner */
-    const int n_surviving = n_queued > 0 ? W->n_surv : 0;
-    if (n_surviving > 0) {
-      const int n = min(n_surviving, COOP_SURV_CAP);
-      for (int idx = lane; idx < n; idx += 64) { /* pass A: distances, atomic minimum of d */
-        STAT_LANE(6);
-        STAT_WAVE(6);
-        const uint4 sv = coop_surv(W)[idx];
-        const int owner = (int)(sv.z & 63u);
-        const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
-        const double *ry = W->ray[owner];
-        const V3 tr0 = {ry[0] - (double)snx * Lx, ry[1] - (double)sny * Ly, ry[2] - (double)snz * Lz};
-        const V3 st = {ry[3], ry[4], ry[5]};
-        const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
-        const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
-        coop_surv_d(W)[idx] = d;
-        if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
+    if (W->n_surv > 0) flush_survivors(ms, r0, step, W, lane, seen_d);
+  }
+  /* ---- stage 4: resolve (simulations.py:986-997) */
+  if (act) {
+    double d = DS_INF;
+    V3 n = {0, 0, 0};
+    if (serial || W->overflow[lane]) {
+      /* this walker's work did not fit the queues: its whole iteration again, by its own lane */
+      STAT_LANE(9);
+      STAT_WAVE(9);
+      BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0, false, {0, 0, 0}};
+      SubvoxelWalk sw; /* recomputed rather than kept in registers through the drain stages */
+      CullBox cbx;
+      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cbx);
+      iteration_serial(ms, sw, r0, step, xs, ys, zs, best);
+      d = best.d;
+      if (d <= step_l) {
+        const double *rec = ms.tri + (int64_t)best.tri * 9;
+        n = cross3(load_v3(rec + 3), load_v3(rec + 6));
       }
-      wave_sync();
-      T_MARK(W, lane, 5);
-      for (int idx = lane; idx < n; idx += 64) { /* pass B: among equal d the earliest (visit, position) */
-        const uint4 sv = coop_surv(W)[idx];
-        const int owner = (int)(sv.z & 63u);
-        const double d = coop_surv_d(W)[idx];
-        if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner])
-          atomicMin(&W->best_key[owner], ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y);
-      }
-      wave_sync();
-      for (int idx = lane; idx < n; idx += 64) { /* pass C: the winner publishes its triangle */
-        const uint4 sv = coop_surv(W)[idx];
-        const int owner = (int)(sv.z & 63u);
-        const double d = coop_surv_d(W)[idx];
-        if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
-            ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner]) {
-          W->best_tri[owner] = (int)sv.x;
-          /* the record is still in the vector L1: publish E1 x E2 so that the owner does not
-           * have to fetch the triangle again before it can reflect */
-          const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
-          const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
-          double *bn = coop_best_n(W) + 3 * owner;
-          bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
-        }
-      }
-      wave_sync();
-      T_MARK(W, lane, 6);
-    }
-    if (act && !serial_all) {
-      if (W->overflow[lane]) {
-        /* a survivor was dropped: redo this walker's iteration serially (keeps every candidate) */
-        STAT_LANE(9);
-        STAT_WAVE(9);
-        best.d = DS_INF;
-        best.visit = 0x7fffffff;
-        best.pos = 0x7fffffff;
-        SubvoxelWalk sw; /* recomputed rather than kept in registers through the drain stages */
-        CullBox cb0;
-        segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
-        enumerate_cells_serial(ms, sw, cb0, r0, step, xs, ys, zs, best);
-      } else {
-        const unsigned long long bd = W->best_d[lane];
-        if (bd != 0x7ff0000000000000ULL) {
-          const unsigned long long key = W->best_key[lane];
-          const double d_pool = __longlong_as_double((long long)bd);
-          const int v_pool = (int)(key >> 32), p_pool = (int)(key & 0xffffffffu);
-          offer_hit(best, d_pool, v_pool, p_pool, W->best_tri[lane]);
-          if (best.d == d_pool && best.visit == v_pool && best.pos == p_pool) { /* the pool's winner is the overall winner */
-            best.have_n = true;
-            const double *bn = coop_best_n(W) + 3 * lane;
-            best.n.x = bn[0], best.n.y = bn[1], best.n.z = bn[2];
-          }
-        }
+    } else {
+      const unsigned long long bd = W->best_d[lane];
+      if (bd != 0x7ff0000000000000ULL) {
+        const double *bn = W->best_n[lane];
+        d = __longlong_as_double((long long)bd);
+        n.x = bn[0], n.y = bn[1], n.z = bn[2];
       }
     }
     T_MARK(W, lane, 7);
-    /* ---- stage 4: resolve (simulations.py:986-997) */
-    if (act) {
-      if (best.d > step_l) {
-        finished = true; /* check_intersection = False */
-      } else {
-        bool reflect = p.perm_prob < rng_uniform_f64(rng);
-        V3 n = best.n;
-        if (!best.have_n) {
-          const double *rec = ms.tri + (int64_t)best.tri * 9;
-          n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
-        }
-        normalize3(n);
-        if (reflect)
-          reflection(r0, step, best.d, n, p.eps);
-        else
-          crossing(r0, step, best.d, n, p.eps);
-        step_l -= best.d;
-        if (!(step_l > 0 && iter_idx < p.max_iter)) finished = true; /* the while-condition of the next pass */
-      }
+    if (d > step_l) {
+      finished = true; /* check_intersection = False */
+    } else {
+      const bool reflect = p.perm_prob < rng_uniform_f64(rng);
+      normalize3(n);
+      if (reflect)
+        reflection(r0, step, d, n, p.eps);
+      else
+        crossing(r0, step, d, n, p.eps);
+      step_l -= d;
+      if (!(step_l > 0 && iter_idx < p.max_iter)) finished = true; /* the while-condition of the next pass */
     }
-    T_MARK(W, lane, 8);
   }
+  T_MARK(W, lane, 8);
   return finished;
 }
 
