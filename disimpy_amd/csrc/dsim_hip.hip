@@ -706,13 +706,16 @@ extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_ve
 /* The scalar-load (SMEM) gradient path was measured at half the speed of the LDS tiles
  * (C2: 3.1e10 vs 6.0e10 spin-steps/s); its kernels are only instantiated when the library is
  * built with -DDSIM_SMEM_GRADIENT (halves the build time otherwise). */
+/* cooperative mesh kernels with at most this many phase accumulators run at 4 waves/SIMD */
+#define COOP4_MAX_MB 2
+
 template <int GEOM, int MB>
 static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {
   if (GEOM == GEOM_MESH && coop) {
     /* the wave queues need more than the default 64 KB of dynamic LDS */
-    auto k0 = walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
+    auto k0 = MB <= COOP4_MAX_MB ? walk_kernel_coop4<(MB <= COOP4_MAX_MB ? MB : 1), 0> : walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
 #ifdef DSIM_SMEM_GRADIENT
-    auto k1 = walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH>;
+    auto k1 = MB <= COOP4_MAX_MB ? walk_kernel_coop4<(MB <= COOP4_MAX_MB ? MB : 1), 1> : walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH>;
     auto k = gsrc ? k1 : k0;
 #else
     auto k = k0;
@@ -847,10 +850,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   const size_t lds_fixed = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1)) * sizeof(double) +
                            (coop ? (size_t)(block / 64) * sizeof(CoopWave) : 0);
   if (coop) {
-    /* three workgroups per CU (3 x 53 KB of the 160 KB LDS; the kernel needs < 168 VGPRs): the
-     * gradient tile gets what the wave queues leave; when that is less than 16 time steps, two
-     * workgroups per CU (2 x 80 KB) and a tile of at most 4 KB */
-    const size_t third = 41 * 1280, half = 80 * 1024 /* LDS is allocated in 1280-byte granules */, per_step = (size_t)mb * 32;
+    /* four workgroups per CU for the 128-VGPR kernels (4 x 40 KB of the 160 KB LDS), else three
+     * (3 x 51 KB): the gradient tile gets what the wave queues leave; when that is less than 16
+     * time steps, two workgroups per CU (2 x 80 KB) and a tile of at most 4 KB */
+    const size_t third = mb <= COOP4_MAX_MB ? 32 * 1280 : 41 * 1280;
+    const size_t half = 80 * 1024 /* LDS is allocated in 1280-byte granules */, per_step = (size_t)mb * 32;
     size_t room = lds_fixed < third ? third - lds_fixed : 0;
     if (room < 16 * per_step) room = std::min<size_t>(lds_fixed < half ? half - lds_fixed : 0, 4096);
     tile = std::min(tile, std::max(1, (int)(room / per_step)));

@@ -28,23 +28,26 @@
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
-#define COOP_ITEM_CAP 448
+#define COOP_ITEM_CAP 256
 #define COOP_SURV_CAP 128
 #define COOP_SVQ_CAP 448
 #define COOP_CELLQ_CAP 256
 
-/* Per-wavefront scratch in LDS (10.1 KB: three 256-thread workgroups per CU).  The owners' cull
- * boxes and rays are NOT here: they stay in the owners' registers and the lane that works on an
- * item reads them with ds_bpermute (__shfl), which costs LDS bandwidth but no LDS space. */
+/* Per-wavefront scratch in LDS (8.1 KB).  The owners' cull boxes and rays are NOT here: they
+ * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
+ * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
   unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)      0.5 KB */
   unsigned long long best_key[64];      /* (visit << 32) | list position of the winner                  0.5 KB */
   double best_n[64][3];                 /* E1 x E2 of the winner's triangle (un-normalised normal)      1.5 KB */
-  uint2 items[COOP_ITEM_CAP];           /* subvoxel tasks {owner|visit|shifts, x | y << 10 | z << 20} (stage 1a -> 1b), then
-                                           items {first record | (count-1) << 30, owner|visit|shifts} (1c -> 2)  3.5 KB */
   uint2 cellq[COOP_CELLQ_CAP];          /* cell tasks {owner|visit|shifts, index into cell_range  or
                                            0x80000000 | subvoxel (range stored inline)} (1b -> 1c)      2.0 KB */
-  uint4 surv[COOP_SURV_CAP];            /* survivors {triangle, list position, owner|visit|shifts, 0}   2.0 KB */
+  /* the next four arrays (3.5 KB) also hold, between stages 1a and 1b, the subvoxel tasks
+   * {owner|visit|shifts, x | y << 10 | z << 20} */
+  uint2 items[COOP_ITEM_CAP];           /* items {first record | (count-1) << 30, owner|visit|shifts} (1c -> 2) */
+  unsigned surv_tri[COOP_SURV_CAP];     /* survivors (2 -> 3): triangle,                                       */
+  unsigned surv_pos[COOP_SURV_CAP];     /*   position in the reference's list,                                 */
+  unsigned surv_tag[COOP_SURV_CAP];     /*   owner|visit|shifts                                                */
   unsigned char overflow[64];           /* some work of this owner did not fit a queue: redo serially          */
   int n_surv, n_svq, n_cellq, pad;
 #ifdef DSIM_TIMERS
@@ -52,11 +55,10 @@ struct CoopWave {
   unsigned long long tpad;
 #endif
 };
-static_assert(COOP_SVQ_CAP <= COOP_ITEM_CAP, "subvoxel tasks share the item queue");
+static_assert(COOP_SVQ_CAP * 8 <= COOP_ITEM_CAP * 8 + COOP_SURV_CAP * 12, "subvoxel tasks share the item and survivor queues");
 static_assert(COOP_SURV_CAP <= 128, "stage 3 keeps two distances per lane in registers");
 
 DSD uint2 *coop_items(CoopWave *W) { return W->items; }
-DSD uint4 *coop_surv(CoopWave *W) { return W->surv; }
 DSD uint2 *coop_svq(CoopWave *W) { return W->items; }
 DSD uint2 *coop_cellq(CoopWave *W) { return W->cellq; }
 
@@ -256,7 +258,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
     const int idx = trip * 64 + lane;
     const bool valid = idx < n_surv;
     uint4 sv = make_uint4(0u, 0u, 0u, 0u);
-    if (valid) sv = coop_surv(W)[idx];
+    if (valid) sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
     const int owner = (int)(sv.z & 63u);
     V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
     const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
@@ -284,7 +286,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   for (int trip = 0; trip < 2; trip++) { /* pass B: among equal d the earliest (visit, position) */
     const int idx = trip * 64 + lane;
     if (idx >= n_surv) continue;
-    const uint4 sv = coop_surv(W)[idx];
+    const uint4 sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
     const int owner = (int)(sv.z & 63u);
     const double d = my_d[trip];
     if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner])
@@ -295,7 +297,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   for (int trip = 0; trip < 2; trip++) { /* pass C: the winner publishes its triangle's normal */
     const int idx = trip * 64 + lane;
     if (idx >= n_surv) continue;
-    const uint4 sv = coop_surv(W)[idx];
+    const uint4 sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
     const int owner = (int)(sv.z & 63u);
     const double d = my_d[trip];
     if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
@@ -498,9 +500,11 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         for (int u = 0; u < 4; u++) {
           if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb) && !ABLATE(3)) {
             const int slot = atomicAdd(&W->n_surv, 1);
-            if (slot < COOP_SURV_CAP)
-              coop_surv(W)[slot] = make_uint4((unsigned)__float_as_int(q2[u].z), (unsigned)__float_as_int(q2[u].w), it.y, 0u);
-            else
+            if (slot < COOP_SURV_CAP) {
+              W->surv_tri[slot] = (unsigned)__float_as_int(q2[u].z);
+              W->surv_pos[slot] = (unsigned)__float_as_int(q2[u].w);
+              W->surv_tag[slot] = it.y;
+            } else
               W->overflow[owner] = 1;
           }
         }
