@@ -713,13 +713,10 @@ template <int GEOM, int MB>
 static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {
   if (GEOM == GEOM_MESH && coop) {
     /* the wave queues need more than the default 64 KB of dynamic LDS */
-    auto k0 = MB <= COOP4_MAX_MB ? walk_kernel_coop4<(MB <= COOP4_MAX_MB ? MB : 1), 0> : walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
-#ifdef DSIM_SMEM_GRADIENT
-    auto k1 = MB <= COOP4_MAX_MB ? walk_kernel_coop4<(MB <= COOP4_MAX_MB ? MB : 1), 1> : walk_kernel<GEOM, MB, 1, GEOM == GEOM_MESH>;
-    auto k = gsrc ? k1 : k0;
-#else
-    auto k = k0;
-#endif
+    /* MB <= COOP4_MAX_MB: the 4-waves/SIMD kernel; it reads the gradient samples from global memory
+     * with the lane's own time index (32 or 64 bytes per step out of the L1), so there is no
+     * LDS tile and no workgroup barrier in the time loop */
+    auto k = MB <= COOP4_MAX_MB ? walk_kernel_coop4<(MB <= COOP4_MAX_MB ? MB : 1), 1> : walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     k<<<grid, block, lds, s>>>(p);
@@ -849,18 +846,20 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
   const size_t lds_fixed = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1)) * sizeof(double) +
                            (coop ? (size_t)(block / 64) * sizeof(CoopWave) : 0);
-  if (coop) {
-    /* four workgroups per CU for the 128-VGPR kernels (4 x 40 KB of the 160 KB LDS), else three
-     * (3 x 51 KB): the gradient tile gets what the wave queues leave; when that is less than 16
-     * time steps, two workgroups per CU (2 x 80 KB) and a tile of at most 4 KB */
-    const size_t third = mb <= COOP4_MAX_MB ? 32 * 1280 : 41 * 1280;
-    const size_t half = 80 * 1024 /* LDS is allocated in 1280-byte granules */, per_step = (size_t)mb * 32;
+  const bool coop4 = coop && mb <= COOP4_MAX_MB;
+  if (coop4) {
+    tile = t_end - t_begin; /* gradient from global memory: one "tile" per launch, no LDS */
+  } else if (coop) {
+    /* three workgroups per CU (3 x 51 KB of the 160 KB LDS, allocated in 1280-byte granules): the
+     * gradient tile gets what the wave queues leave; when that is less than 16 time steps, two
+     * workgroups per CU (2 x 80 KB) and a tile of at most 4 KB */
+    const size_t third = 41 * 1280, half = 80 * 1024, per_step = (size_t)mb * 32;
     size_t room = lds_fixed < third ? third - lds_fixed : 0;
     if (room < 16 * per_step) room = std::min<size_t>(lds_fixed < half ? half - lds_fixed : 0, 4096);
     tile = std::min(tile, std::max(1, (int)(room / per_step)));
   }
   p.tile_steps = tile;
-  size_t lds = lds_fixed + (size_t)tile * mb * 4 * sizeof(double);
+  size_t lds = lds_fixed + (coop4 ? 0 : (size_t)tile * mb * 4 * sizeof(double));
   if (lds > (coop ? 160u : 64u) * 1024u) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   const int grid = grid_for(h->n, block);
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
@@ -872,7 +871,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       for (int k = 0; k < 3; k++)
         if (h->mesh.inv_h[k] > 0) hmin = std::min(hmin, 1.0 / h->mesh.inv_h[k]);
       double r = h->step_l > 0 ? hmin / h->step_l : 1e3;
-      resort = (int)std::min(1024.0, std::max(32.0, 0.75 * r * r));
+      resort = (int)std::min(1024.0, std::max(96.0, 0.75 * r * r));
     }
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;

@@ -383,7 +383,7 @@ DSD void walk_body(const WalkParams &p) {
   if (GEOM == GEOM_MESH) n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
   double *gt = bounds + ((n_bounds + 1) & ~1);     /* gradient tile, 16-byte aligned  */
   /* mesh, cooperative traversal: one CoopWave per wavefront behind the gradient tile */
-  CoopWave *coop = reinterpret_cast<CoopWave *>(gt + (size_t)p.tile_steps * MB * 4) + (threadIdx.x >> 6);
+  CoopWave *coop = reinterpret_cast<CoopWave *>(gt + (GSRC == 0 ? (size_t)p.tile_steps * MB * 4 : 0)) + (threadIdx.x >> 6);
 
   for (int i = threadIdx.x; i < DS_LOG_TABLE_DOUBLES; i += blockDim.x) log_tab[i] = ds_log_table_dev[i];
   for (int i = threadIdx.x; i < DS_COS_TABLE_DOUBLES; i += blockDim.x) cos_tab[i] = ds_cos_table_dev[i];
