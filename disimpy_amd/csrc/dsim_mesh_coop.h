@@ -32,6 +32,7 @@
 #define COOP_SURV_CAP 128
 #define COOP_SVQ_CAP 448
 #define COOP_CELLQ_CAP 256
+#define COOP_NO_SHIFT 0x20820u /* tag >> 14 when all three image numbers are 0 (stored + 32, 6 bits each) */
 
 /* Per-wavefront scratch in LDS (8.1 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
@@ -265,8 +266,10 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
     if (!valid) continue;
     STAT_LANE(6);
     STAT_WAVE(6);
-    const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
-    tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
+    if ((sv.z >> 14) != COOP_NO_SHIFT) { /* x - 0.0 == x bit for bit, so the unshifted case skips the arithmetic */
+      const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
+      tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
+    }
     const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
     const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
     my_d[trip] = d;
@@ -384,8 +387,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel (or no task for this lane) */
       int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
       if (mg.x > 0) {
-        const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
-        cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        if ((e.x >> 14) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
+          const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
+          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        }
         k = 1 << mg.y;
         const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
         a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
@@ -486,8 +491,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         STAT_LANE(4);
         STAT_WAVE(4);
         const int first_rec = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
-        const int snx = (int)((it.y >> 14) & 63u) - 32, sny = (int)((it.y >> 20) & 63u) - 32, snz = (int)(it.y >> 26) - 32;
-        cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        if ((it.y >> 14) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
+          const int snx = (int)((it.y >> 14) & 63u) - 32, sny = (int)((it.y >> 20) & 63u) - 32, snz = (int)(it.y >> 26) - 32;
+          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        }
         float4 q0[4], q1[4], q2[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
