@@ -364,6 +364,29 @@ def test_mesh_neuron_bit_identical_and_contained(lib, oracle_exact, traversal):
     assert (gpu["pos"].max(axis=0) < sub.voxel_size).all() and (gpu["pos"].min(axis=0) > 0).all()
 
 
+@pytest.mark.parametrize("n_sv,dt", [([10, 10, 10], 3e-3), ([3, 3, 3], 3e-2)])
+def test_mesh_work_beyond_the_wave_queues(lib, oracle_exact, n_sv, dt):
+    """Coarse index of the neuron + steps of 6 / 19 um: every walker reaches dozens of micro-cells
+    with hundreds of records, far more than the cooperative traversal's LDS queues hold per pass
+    (256 cell tasks, 256 items, 128 survivors).  Items and survivors are then drained in rounds,
+    walkers whose cell tasks do not fit are redone serially by their own lane; results must not
+    change (checked once with the -DDSIM_STATS build: rounds, mid-drain flushes and serial
+    redo all occur in these two configurations)."""
+    from disimpy_amd import simulations, substrates
+
+    m = golden("neuron_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), True, init_pos="intra", n_sv=np.array(n_sv), quiet=True)
+    n, T = 512, 12
+    step_l = float(np.sqrt(6 * D * dt))
+    g = np.ones((1, T, 3))
+    pos0 = simulations._fill_mesh(n, sub, True, 7)
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 5, kw, mesh=ma, tuning=dict(mesh_traversal=2))
+    _assert_identical(gpu, ref)
+
+
 @pytest.mark.parametrize("periodic", [True, False])
 @pytest.mark.parametrize("intra", [True, False])
 def test_fill_mesh_identical_to_oracle(lib, oracle_exact, periodic, intra):
