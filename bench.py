@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: spin-steps/s of the fused random-walk kernels.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5|c5b]
 
 One "step" = one pass of the hot path over one batch: every walker of this
 rank's shard is advanced through the whole gradient waveform (T time steps, one
@@ -75,6 +75,62 @@ def packed_cylinders(nside=8, pitch=2.5e-6, radius=1e-6, height=5e-6, nseg=32):
     return np.array(verts), np.array(faces, dtype=np.int64)
 
 
+def split_longest_edges(vertices, faces, n_target):
+    """Geometry-preserving refinement (SURVEY.md 8d, C5 option b): the longest edge is cut at its
+    midpoint, together with every triangle that shares it (no T-junctions, the surface stays
+    watertight and its shape unchanged), until the mesh has n_target triangles."""
+    import heapq
+
+    verts = [tuple(v) for v in np.asarray(vertices, dtype=np.float64)]
+    tris = [tuple(int(i) for i in f) for f in faces]
+    alive = [True] * len(tris)
+    edge_faces = {}
+
+    def key(a, b):
+        return (a, b) if a < b else (b, a)
+
+    def length2(e):
+        a, b = np.array(verts[e[0]]), np.array(verts[e[1]])
+        return float(np.sum((a - b) ** 2))
+
+    heap = []
+
+    def add_face(fi):
+        a, b, c = tris[fi]
+        for e in (key(a, b), key(b, c), key(c, a)):
+            if e not in edge_faces:
+                edge_faces[e] = set()
+                heapq.heappush(heap, (-length2(e), e))
+            edge_faces[e].add(fi)
+
+    for fi in range(len(tris)):
+        add_face(fi)
+    n_alive = len(tris)
+    while n_alive < n_target and heap:
+        _, e = heapq.heappop(heap)
+        fs = [fi for fi in edge_faces.pop(e, ()) if alive[fi]]
+        if not fs:
+            continue
+        a, b = e
+        m = len(verts)
+        verts.append(tuple((np.array(verts[a]) + np.array(verts[b])) / 2))
+        for fi in fs:
+            t = tris[fi]
+            alive[fi] = False
+            for ed in (key(t[0], t[1]), key(t[1], t[2]), key(t[2], t[0])):
+                if ed in edge_faces:
+                    edge_faces[ed].discard(fi)
+            i = [k for k in range(3) if {t[k], t[(k + 1) % 3]} == {a, b}][0]
+            p, q, r = t[i], t[(i + 1) % 3], t[(i + 2) % 3]  # edge p -> q is cut, winding kept
+            for nt in ((p, m, r), (m, q, r)):
+                tris.append(nt)
+                alive.append(True)
+                add_face(len(tris) - 1)
+            n_alive += 1
+    out = np.array([t for t, ok in zip(tris, alive) if ok], dtype=np.int64)
+    return np.array(verts), out
+
+
 def make_workload(name, n_walkers):
     """Returns dict(kind, gradient, dt, D, substrate, label, M, T)."""
     from disimpy_amd import gradients, substrates
@@ -104,6 +160,14 @@ def make_workload(name, n_walkers):
         sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), True, init_pos="intra", quiet=True)
         return dict(gradient=gradient, dt=dt, D=D, substrate=sub,
                     label="C5 neuron mesh (29688 tris, periodic, intra), %d spins x 10000 steps, M=1" % n_walkers)
+    if name == "c5b":
+        gradient, dt = misst_waveform(10000, np.array([1e9]))
+        m = np.load(os.path.join(ROOT, "tests", "golden", "neuron_mesh.npz"))
+        v, f = split_longest_edges(m["vertices"], m["faces"], 50000)
+        sub = substrates.mesh(v, f, True, init_pos="intra", quiet=True)
+        return dict(gradient=gradient, dt=dt, D=D, substrate=sub,
+                    label="C5b neuron mesh refined to %d tris (longest edges split), periodic, intra, %d spins x 10000 "
+                          "steps, M=1" % (len(f), n_walkers))
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -159,7 +223,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c5b"])
     ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-size", type=int, default=0)
@@ -194,7 +258,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = local_rank if world > 1 else 0
 
-    default_walkers = {"c1": 1000, "c2": 1_000_000, "c3": 1_000_000, "c4": 1_000_000, "c5": 1_000_000}
+    default_walkers = {"c1": 1000, "c2": 1_000_000, "c3": 1_000_000, "c4": 1_000_000, "c5": 1_000_000, "c5b": 1_000_000}
     n_local = args.walkers or default_walkers[args.workload]
     n_total = n_local * world
     w = make_workload(args.workload, n_local)
@@ -262,7 +326,12 @@ def main():
     # roofline of the dominant kernel (walk_kernel): algorithmic bytes per launch / launch duration
     n_launch = max(1, launches[-1])
     meas_per_launch = min(M, 32 if not args.meas_per_pass else args.meas_per_pass)
-    bytes_per_launch = (80.0 + 16.0 * meas_per_launch) * n_local * T
+    # a launch covers all walkers, meas_per_launch measurements and T * passes / n_launch time steps
+    # (mesh runs are cut into one launch per re-sort interval; M > 32 needs several passes)
+    mb_pow2 = 1 << max(0, (meas_per_launch - 1).bit_length())
+    passes = -(-M // meas_per_launch)
+    steps_per_launch = T * passes / n_launch
+    bytes_per_launch = (80.0 + 16.0 * meas_per_launch) * n_local * steps_per_launch
     avg_launch_ms = float(np.mean(kernel_ms)) / n_launch
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
@@ -288,7 +357,8 @@ def main():
             "FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated: profiles/hbm_traffic.json)",
             "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "kernel": "walk_kernel<%s,%d>" % (sub.type, 1 << max(0, (meas_per_launch - 1).bit_length())),
+            "kernel": ("walk_kernel_coop4<%d>" % mb_pow2 if sub.type == "mesh" and mb_pow2 <= 2 and args.mesh_traversal != 1
+                       else "walk_kernel<%s,%d>" % (sub.type, mb_pow2)),
             "algorithmic_bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch,
             "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
             "note": "time-fused kernel: walker state stays in registers, so real HBM traffic (traffic) is far "
