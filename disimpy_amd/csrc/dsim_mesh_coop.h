@@ -57,7 +57,6 @@ struct CoopWave {
 #endif
 };
 static_assert(COOP_SVQ_CAP * 8 <= COOP_ITEM_CAP * 8 + COOP_SURV_CAP * 12, "subvoxel tasks share the item and survivor queues");
-static_assert(COOP_SURV_CAP <= 128, "stage 3 keeps two distances per lane in registers");
 
 DSD uint2 *coop_items(CoopWave *W) { return W->items; }
 DSD uint2 *coop_svq(CoopWave *W) { return W->items; }
@@ -244,26 +243,25 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
   sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
 }
 
-/* Stage 3: all lanes drain the survivor pool - fp64 Moller-Trumbore test with the owner's ray,
- * minimum per owner by 64-bit LDS atomics on the bit pattern of d, ties resolved by a second
- * atomic pass on (visit, list position), the winner publishes its normal.  May run several
- * times per pass (the pool is flushed whenever it is half full); seen_d is best_d[lane] as of
- * the previous flush.  Every lane of the wavefront must call this. */
-DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWave *W, int lane, unsigned long long &seen_d) {
+/* Stage 3: one trip of fp64 tests over the survivors [base, base + count) of the pool, count <= 64:
+ * Moller-Trumbore test with the owner's ray, minimum per owner by 64-bit LDS atomics on the bit
+ * pattern of d, ties resolved by a second atomic pass on (visit, list position), the winner
+ * publishes its normal.  Runs several times per pass (a full trip whenever the pool holds 64
+ * survivors, the remainder at the end); seen_d is best_d[lane] as of the previous call.  Every
+ * lane of the wavefront must call this.  Leaves W->n_surv = base. */
+DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWave *W, int lane, unsigned long long &seen_d,
+                         int base, int count) {
   const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1;
-  const int n_surv = min(W->n_surv, COOP_SURV_CAP);
-  double my_d[2] = {0, 0}; /* n_surv <= 2 * 64: at most two survivors per lane */
-#pragma unroll
-  for (int trip = 0; trip < 2; trip++) { /* pass A: distances, atomic minimum of d */
-    if (trip * 64 >= n_surv) break;
-    const int idx = trip * 64 + lane;
-    const bool valid = idx < n_surv;
-    uint4 sv = make_uint4(0u, 0u, 0u, 0u);
-    if (valid) sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
-    const int owner = (int)(sv.z & 63u);
-    V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
-    const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
-    if (!valid) continue;
+  const int idx = base + lane;
+  const bool valid = lane < count;
+  uint4 sv = make_uint4(0u, 0u, 0u, 0u);
+  if (valid) sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
+  const int owner = (int)(sv.z & 63u);
+  const unsigned long long key = ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y;
+  V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
+  const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
+  double d = 0;
+  if (valid) { /* pass A: distances, atomic minimum of d */
     STAT_LANE(6);
     STAT_WAVE(6);
     if ((sv.z >> 14) != COOP_NO_SHIFT) { /* x - 0.0 == x bit for bit, so the unshifted case skips the arithmetic */
@@ -271,10 +269,10 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
       tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
     }
     const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
-    const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
-    my_d[trip] = d;
+    d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
     if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
   }
+  if (lane == 0) W->n_surv = base;
   wave_sync();
   T_MARK(W, lane, 5);
   { /* a smaller minimum than at the last flush invalidates the tie-break key of the earlier one */
@@ -285,35 +283,17 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
     }
   }
   wave_sync();
-#pragma unroll
-  for (int trip = 0; trip < 2; trip++) { /* pass B: among equal d the earliest (visit, position) */
-    const int idx = trip * 64 + lane;
-    if (idx >= n_surv) continue;
-    const uint4 sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
-    const int owner = (int)(sv.z & 63u);
-    const double d = my_d[trip];
-    if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner])
-      atomicMin(&W->best_key[owner], ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y);
-  }
+  const bool is_min = valid && d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner];
+  if (is_min) atomicMin(&W->best_key[owner], key); /* pass B: among equal d the earliest (visit, position) */
   wave_sync();
-#pragma unroll
-  for (int trip = 0; trip < 2; trip++) { /* pass C: the winner publishes its triangle's normal */
-    const int idx = trip * 64 + lane;
-    if (idx >= n_surv) continue;
-    const uint4 sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
-    const int owner = (int)(sv.z & 63u);
-    const double d = my_d[trip];
-    if (d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner] &&
-        ((((unsigned long long)((sv.z >> 6) & 255u)) << 32) | (unsigned long long)sv.y) == W->best_key[owner]) {
-      /* the record is still in the vector L1: publish E1 x E2 so that the owner does not have to
-       * fetch the triangle before it can reflect ((A-B)x(A-C) == E1 x E2 bit for bit) */
-      const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
-      const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
-      double *bn = W->best_n[owner];
-      bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
-    }
+  if (is_min && key == W->best_key[owner]) { /* pass C: the winner publishes its triangle's normal */
+    /* the record is still in the vector L1: publish E1 x E2 so that the owner does not have to
+     * fetch the triangle before it can reflect ((A-B)x(A-C) == E1 x E2 bit for bit) */
+    const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+    const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
+    double *bn = W->best_n[owner];
+    bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
   }
-  if (lane == 0) W->n_surv = 0;
   wave_sync();
   T_MARK(W, lane, 6);
 }
@@ -517,12 +497,16 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         }
         }
         T_MARK(W, lane, 4);
-        /* a trip adds 15 survivors on average and 256 at most: flush the pool once it is half full */
+        /* a trip adds 15 survivors on average and 256 at most: whenever the pool holds 64, its last
+         * 64 entries make one full trip of fp64 tests */
         wave_sync();
-        if (W->n_surv > COOP_SURV_CAP / 2) flush_survivors(ms, r0, step, W, lane, seen_d);
+        for (int n = min(W->n_surv, COOP_SURV_CAP); n >= 64; n -= 64) flush_survivors(ms, r0, step, W, lane, seen_d, n - 64, 64);
       }
     }
-    if (W->n_surv > 0) flush_survivors(ms, r0, step, W, lane, seen_d);
+    {
+      const int n = min(W->n_surv, COOP_SURV_CAP); /* < 64 */
+      if (n > 0) flush_survivors(ms, r0, step, W, lane, seen_d, 0, n);
+    }
   }
   /* ---- stage 4: resolve (simulations.py:986-997) */
   if (act) {
