@@ -405,9 +405,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     uint2 *items = coop_items(W);
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     int cursor = 0;
+    int n_items = 0;        /* items waiting in the queue (wave-uniform) */
+    bool drain_all = false; /* the next cell does not fit behind the waiting items */
     while (cursor < n_cells) {
       /* -- 1c: up to 64 cell tasks per round, one per lane */
-      int n_items = 0;
       while (cursor < n_cells && n_items <= COOP_ITEM_CAP - 64) {
         const int idx = cursor + lane;
         uint2 e = make_uint2(0xffffffffu, 0u);
@@ -434,7 +435,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const unsigned long long fits = __ballot(n_items + incl <= COOP_ITEM_CAP);
         const int n_take = fits == ~0ULL ? 64 : (int)__ffsll((long long)~fits) - 1; /* the lanes that fit form a prefix */
         if (n_take == 0) {
-          if (n_items > 0) break; /* drain first, then retry with an empty queue */
+          if (n_items > 0) { /* drain first, then retry with an empty queue */
+            drain_all = true;
+            break;
+          }
           /* a single cell with more records than the whole queue holds: its owner works serially */
           if (lane == 0) W->overflow[(int)(e.x & 63u)] = 1;
           cursor += 1;
@@ -452,10 +456,14 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         if (n_take < 64) break;
       }
       T_MARK(W, lane, 13);
-      if (n_items == 0) continue;
+      /* -- 2: all lanes drain the item queue: float32 AABB + plane culling against the owner's box.
+       * While more cells are coming only full trips of 64 items are drained (the tail of the queue);
+       * the remainder waits at the head for the next round */
+      const int start = (cursor >= n_cells || drain_all) ? 0 : (n_items & 63);
+      drain_all = false;
+      if (start == n_items) continue;
       wave_sync();
-      /* -- 2: all lanes drain the item queue: float32 AABB + plane culling against the owner's box */
-      for (int first = 0; first < n_items; first += 64) {
+      for (int first = start; first < n_items; first += 64) {
         const int idx = first + lane;
         const bool valid = idx < n_items;
         uint2 it = make_uint2(0u, 0u);
@@ -502,6 +510,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         wave_sync();
         for (int n = min(W->n_surv, COOP_SURV_CAP); n >= 64; n -= 64) flush_survivors(ms, r0, step, W, lane, seen_d, n - 64, 64);
       }
+      n_items = start;
     }
     {
       const int n = min(W->n_surv, COOP_SURV_CAP); /* < 64 */
