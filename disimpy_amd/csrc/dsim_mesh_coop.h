@@ -62,6 +62,18 @@ DSD uint2 *coop_items(CoopWave *W) { return W->items; }
 DSD uint2 *coop_svq(CoopWave *W) { return W->items; }
 DSD uint2 *coop_cellq(CoopWave *W) { return W->cellq; }
 
+/* inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS crossbar): Kogge-Stone
+ * inside every row of 16 lanes, then the row totals are carried into the following rows */
+DSD int wave_inclusive_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
+  return v;
+}
+
 DSD double shfl_f64(double v, int src) {
   const long long b = __double_as_longlong(v);
   const int lo = __shfl((int)(b & 0xffffffffLL), src, 64), hi = __shfl((int)(b >> 32), src, 64);
@@ -426,12 +438,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           STAT_LANE(3);
           STAT_WAVE(3);
         }
-        int incl = nb; /* inclusive prefix sum over the lanes */
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int up = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += up;
-        }
+        const int incl = wave_inclusive_sum(nb);
         const unsigned long long fits = __ballot(n_items + incl <= COOP_ITEM_CAP);
         const int n_take = fits == ~0ULL ? 64 : (int)__ffsll((long long)~fits) - 1; /* the lanes that fit form a prefix */
         if (n_take == 0) {
@@ -451,7 +458,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), e.x);
           }
         }
-        n_items += __shfl(incl, n_take - 1, 64);
+        n_items += __builtin_amdgcn_readlane(incl, n_take - 1);
         cursor += n_take;
         if (n_take < 64) break;
       }
