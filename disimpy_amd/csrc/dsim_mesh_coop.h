@@ -50,7 +50,7 @@ struct CoopWave {
   unsigned surv_pos[COOP_SURV_CAP];     /*   position in the reference's list,                                 */
   unsigned surv_tag[COOP_SURV_CAP];     /*   owner|visit|shifts                                                */
   unsigned char overflow[64];           /* some work of this owner did not fit a queue: redo serially          */
-  int n_surv, n_svq, n_cellq, pad;
+  int n_surv, n_svq, pad[2];
 #ifdef DSIM_TIMERS
   unsigned long long tacc[16], tlast;
   unsigned long long tpad;
@@ -329,7 +329,6 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   if (lane == 0) {
     W->n_surv = 0;
     W->n_svq = 0;
-    W->n_cellq = 0;
   }
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
   W->best_key[lane] = ~0ULL;
@@ -356,6 +355,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   T_MARK(W, lane, 2);
   wave_sync();
   /* ---- stage 1b: all lanes look the subvoxels up and list the micro-cells the cull box reaches */
+  int n_cellq = 0; /* cell tasks queued (wave-uniform; may exceed the capacity: the excess was not written) */
   {
     const int n = min(W->n_svq, COOP_SVQ_CAP);
     const uint2 *svq = coop_svq(W);
@@ -376,9 +376,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       }
       CullBox cb = {__shfl(cb0.lox, owner, 64), __shfl(cb0.loy, owner, 64), __shfl(cb0.loz, owner, 64), __shfl(cb0.hix, owner, 64),
                     __shfl(cb0.hiy, owner, 64), __shfl(cb0.hiz, owner, 64), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      if (mg.x == 0 || ABLATE(1)) continue; /* empty subvoxel (or no task for this lane) */
+      const bool has = mg.x != 0 && !ABLATE(1); /* not an empty subvoxel (or no task for this lane) */
       int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
-      if (mg.x > 0) {
+      if (mg.x > 0 && !ABLATE(1)) {
         if ((e.x >> 14) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
           const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
           cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
@@ -389,9 +389,14 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
         c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
       }
-      const int ncell = (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1);
-      const int base = atomicAdd(&W->n_cellq, ncell);
+      /* queue slots from a prefix sum over the lanes (DPP; no LDS atomic) */
+      const int ncell = has ? (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1) : 0;
+      const int incl = wave_inclusive_sum(ncell);
+      const int base = n_cellq + incl - ncell;
+      n_cellq += __builtin_amdgcn_readlane(incl, 63);
+      if (!has) continue;
       if (base + ncell > COOP_CELLQ_CAP) {
+        /* queue full: neutralise the part of the reservation that lies inside the queue */
         for (int j = base; j < COOP_CELLQ_CAP; j++) cq[j] = make_uint2(0xffffffffu, 0u);
         W->overflow[owner] = 1;
         continue;
@@ -412,7 +417,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
    * is nearly full, the items are drained into the survivor pool, the pool is flushed (fp64 tests,
    * per-owner minimum) when it is half full - so no queue size limits the amount of work per pass */
   {
-    const int n_cells = min(W->n_cellq, COOP_CELLQ_CAP);
+    const int n_cells = min(n_cellq, COOP_CELLQ_CAP);
     const uint2 *cq = coop_cellq(W);
     uint2 *items = coop_items(W);
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
