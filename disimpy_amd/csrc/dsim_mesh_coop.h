@@ -3,27 +3,40 @@
  * Per-lane traversal (step_mesh in dsim_kernels.h) pays, at every loop level,
  * for the slowest of the 64 lanes: measured on the neuron (tools/mesh_stats.py)
  * a wavefront makes 47 record-batch trips per step with 8.6 lanes active and 45
- * Moller-Trumbore trips with 2.2 lanes active.  Here the 64 walkers of a
- * wavefront pool their candidate work in LDS:
+ * Moller-Trumbore trips with 2.2 lanes active.  Here ONE pass of the reference's
+ * reflect loop (simulations.py:924-997) is done for the 64 walkers of a
+ * wavefront together, as flat loops over work queues that ALL lanes drain:
  *
- *   stage 1  every walker ("owner") enumerates the micro-cells its segment
- *            reaches and appends 4-record work items to the wave's item queue;
- *   stage 2  all 64 lanes drain the queue round-robin - each item is 4 records
- *            tested (float32 AABB + plane) against the OWNER's cull box read
- *            from LDS; survivors are appended to the owner's survivor slots;
- *   stage 3  all lanes drain the survivor pool: fp64 Moller-Trumbore test with
- *            the OWNER's ray (LDS), minimum per owner by 64-bit LDS atomics on
- *            the bit pattern of d, ties resolved by a second atomic pass;
- *   stage 4  reflection / crossing per walker, then the next iteration for
- *            the walkers that hit something (simulations.py:924-997).
+ *   stage 1a  every walker ("owner"): subvoxel limits, float32 cull box, one
+ *             task per subvoxel in range (reference order = visit number);
+ *   stage 1b  any lane per subvoxel task: sv_micro look-up, the micro-cells the
+ *             owner's box reaches -> cell tasks;
+ *   stage 1c  any lane per cell task: cell_range look-up, the record range cut
+ *             into 4-record items (slots from a wave prefix sum);
+ *   stage 2   any lane per item: 4 records tested (float32 AABB + plane)
+ *             against the OWNER's cull box -> survivor pool;
+ *   stage 3   any lane per survivor: fp64 Moller-Trumbore test with the OWNER's
+ *             ray, minimum per owner by 64-bit LDS atomics on the bit pattern
+ *             of d, ties resolved by a second atomic pass, the winner publishes
+ *             its normal;
+ *   stage 4   reflection / crossing per walker, then the next pass for the
+ *             walkers that hit something.
+ *
+ * Stages 1c-3 run in rounds (cells are expanded while the item queue has room,
+ * items are drained in full trips of 64, the survivor pool is flushed in full
+ * trips of 64), so the queue sizes bound the LDS footprint, not the work per
+ * pass.  The owners' boxes and rays stay in the owners' registers and are read
+ * with ds_bpermute; the kernel then fits 128 VGPRs and 8 KB of LDS per
+ * wavefront, i.e. 4 wavefronts per SIMD.
  *
  * Which triangles are tested, in fp64, against which ray is unchanged, and the
  * minimum keeps the reference's "first visited wins a tie" rule through the
  * explicit key (subvoxel visit number, position in the reference's list), so
- * results stay bit-identical to step_mesh and to the oracle.  Anything that
- * does not fit the queues (more than 255 subvoxels in range, image shifts
- * beyond +-31 voxels, item queue or survivor pool overflow) is handled by the
- * owner itself with the serial scan.
+ * results stay bit-identical to step_mesh and to the oracle.  A walker whose
+ * work cannot be queued (more than 256 subvoxels in range, image shifts beyond
+ * +-31 voxels, cell-task queue full, a single cell with more than 1024 records,
+ * more than 128 survivors from one trip) is redone by its own lane exactly as
+ * the reference does it (iteration_serial).
  */
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
