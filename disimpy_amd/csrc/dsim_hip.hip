@@ -871,7 +871,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       for (int k = 0; k < 3; k++)
         if (h->mesh.inv_h[k] > 0) hmin = std::min(hmin, 1.0 / h->mesh.inv_h[k]);
       double r = h->step_l > 0 ? hmin / h->step_l : 1e3;
-      resort = (int)std::min(1024.0, std::max(96.0, 0.75 * r * r));
+      /* measured (C4, C5): a sort costs about as much as 10 time steps, the lanes of a wavefront stay
+       * in neighbouring subvoxels for several hundred steps, and every launch boundary idles the
+       * lanes that are ahead of their neighbours: 512..1024 steps, longer where walkers move slowly */
+      resort = (int)std::min(1024.0, std::max(512.0, 8.0 * r * r));
     }
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
