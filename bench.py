@@ -335,11 +335,14 @@ def main():
     avg_launch_ms = float(np.mean(kernel_ms)) / n_launch
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
+    valu = None  # the bound that actually holds (rocprofv3 SQ counters of the same workload, profiles/)
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
             if n_local == default_walkers[args.workload] and not args.meas_per_pass:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("bytes_per_launch")
+                prof = json.load(open(tfile)).get(args.workload, {})
+                traffic = prof.get("bytes_per_launch")
+                valu = prof.get("valu")
         except Exception:
             traffic = None
 
@@ -360,7 +363,7 @@ def main():
             "kernel": ("walk_kernel_coop4<%d>" % mb_pow2 if sub.type == "mesh" and mb_pow2 <= 2 and args.mesh_traversal != 1
                        else "walk_kernel<%s,%d>" % (sub.type, mb_pow2)),
             "algorithmic_bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch,
-            "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
+            "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms, "valu": valu,
             "note": "time-fused kernel: walker state stays in registers, so real HBM traffic (traffic) is far "
                     "below the algorithmic bytes of the reference's step-synchronous formulation; the kernel "
                     "is fp64-VALU bound",
