@@ -930,7 +930,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   p.tile_steps = tile;
   size_t lds = lds_fixed + (coop4 ? 0 : (size_t)tile * mb * 4 * sizeof(double));
   if (lds > (coop ? 160u : 64u) * 1024u) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
-  const int grid = grid_for(h->n, block);
+  int grid = grid_for(h->n, block);
+  if (geom == GEOM_MESH) grid = (grid + 255) & ~255; /* XCD-aware group mapping in the kernel */
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
   int resort = 0;
   if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX) {

@@ -391,7 +391,18 @@ DSD void walk_body(const WalkParams &p) {
     for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) bounds[i] = p.mesh.bounds[i];
   const double *xs = bounds, *ys = bounds + p.mesh.nx + 1, *zs = bounds + p.mesh.nx + p.mesh.ny + 2;
 
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  /* Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every
+   * XCD has its own L2.  Mesh walkers are Morton-sorted: an XCD takes runs of 32 consecutive
+   * walker groups (8192 walkers, a compact region of space whose part of the index stays in that
+   * XCD's L2), the runs are dealt to the XCDs in turn so that dense and sparse regions spread
+   * evenly (giving every XCD one contiguous eighth was 11 % slower on the neuron).  The host
+   * rounds the grid up to a multiple of 256; groups beyond the last walker are empty. */
+  int64_t group = blockIdx.x;
+  if (GEOM == GEOM_MESH) {
+    const unsigned slot = blockIdx.x >> 3; /* position in the XCD's own sequence */
+    group = ((int64_t)(slot >> 5) * 8 + (blockIdx.x & 7)) * 32 + (slot & 31);
+  }
+  const int64_t i = group * blockDim.x + threadIdx.x;
   const bool live = i < p.n;
   V3 r = {0, 0, 0};
   Rng rng = {1, 1};
