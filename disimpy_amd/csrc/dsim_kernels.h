@@ -52,7 +52,8 @@ __device__ unsigned long long dsim_timers[16];
 
 /* Timing-ablation switch (-DDSIM_ABLATE, tools/ablate_coop.py; results become wrong, only the
  * timing is of interest): 1 = every subvoxel looks empty, 2 = cells are enumerated but nothing
- * is queued or scanned, 3 = items are culled but survivors are dropped. */
+ * is queued or scanned, 3 = items are culled but survivors are dropped, 4 = as 3 and every lane
+ * reads the same four records (stage 2 without its gather traffic). */
 #ifdef DSIM_ABLATE
 __device__ int dsim_ablate = 0;
 #define ABLATE(n) (dsim_ablate == (n))

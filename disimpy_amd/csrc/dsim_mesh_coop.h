@@ -511,14 +511,14 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         float4 q0[4], q1[4], q2[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int j = first_rec + min(u, cnt - 1);
+          const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
           q0[u] = ms.mrec[3 * j];
           q1[u] = ms.mrec[3 * j + 1];
           q2[u] = ms.mrec[3 * j + 2];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb) && !ABLATE(3)) {
+          if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb) && !ABLATE(3) && !ABLATE(4)) {
             const int slot = atomicAdd(&W->n_surv, 1);
             if (slot < COOP_SURV_CAP) {
               W->surv_tri[slot] = (unsigned)__float_as_int(q2[u].z);

@@ -1,6 +1,11 @@
 """Timing ablation of the cooperative mesh traversal (development build, GPU box):
     make -C disimpy_amd/csrc libdsim_hip_ablate.so
-    DSIM_LIB=disimpy_amd/csrc/libdsim_hip_ablate.so python tools/ablate_coop.py [c5|c4]"""
+    DSIM_LIB=disimpy_amd/csrc/libdsim_hip_ablate.so python tools/ablate_coop.py [c5|c4]
+
+CAVEAT: modes 1-4 switch the reflections off, so confined walkers (C5: inside the neuron) escape
+into empty space within tens of steps and the later steps see no triangles at all - the numbers
+are lower bounds of the stage costs, not a breakdown.  tools/mesh_timers.py (shader-clock timers
+in the intact kernel) is the instrument to trust."""
 import os
 import sys
 
@@ -10,7 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
-MODES = {0: "full", 3: "survivors dropped (no fp64 tests, no reflections)", 2: "cells enumerated, nothing queued",
+MODES = {0: "full", 3: "survivors dropped (no fp64 tests, no reflections)",
+         4: "survivors dropped, all lanes read the same 4 records", 2: "cells enumerated, nothing queued",
          1: "every subvoxel empty (step + lookups + sv_micro load)"}
 
 
