@@ -54,8 +54,33 @@ DSD uint64_t rng_next(Rng &r) {
   return result;
 }
 
-/* numba/cuda/random.py:128-139 */
-DSD double u64_to_unit_f64(uint64_t x) { return (double)(x >> 11) * 0x1p-53; }
+/* numba/cuda/random.py:128-139: (double)(x >> 11) * 2^-53.  The 53-bit integer is split into its
+ * top 21 and low 32 bits; hi * 2^-21 and lo * 2^-53 are exact and do not overlap, so the fma is
+ * exact as well - the same double as the 64-bit shift + u64 -> f64 conversion (two conversions,
+ * two ldexp and an add on gfx950) in 2 integer and 4 floating-point operations. */
+DSD double u64_to_unit_f64(uint64_t x) {
+  const uint32_t hi = (uint32_t)(x >> 43), lo = (uint32_t)(x >> 11);
+  return __builtin_fma((double)lo, 0x1p-53, (double)hi * 0x1p-21);
+}
+
+/* sqrt for the Box-Muller radius and the vector lengths.  For 2^-767 <= x < inf this is the
+ * instruction sequence of the compiler's own correctly rounded fp64 sqrt (v_rsq_f64 + two
+ * Newton steps with exact residuals) WITHOUT the range scaling and special-case selects around
+ * it (8 of 18 instructions) - there they are the identity, so the result is the same bit for
+ * bit; everything else (0, tiny, negative, inf, NaN) takes the generic expansion. */
+DSD double ds_sqrt_dev(double x) {
+  if (!(x >= 0x1p-767 && x < DS_INF)) return __builtin_sqrt(x);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  double d = __builtin_fma(-g, g, x);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
 DSD double rng_uniform_f64(Rng &r) { return u64_to_unit_f64(rng_next(r)); }
 DSD float rng_uniform_f32(Rng &r) { return (float)u64_to_unit_f64(rng_next(r)); }
 
@@ -64,7 +89,7 @@ DSD double rng_normal_f64(Rng &r, const double *log_tab, const double *cos_tab) 
   float u1 = rng_uniform_f32(r);
   float u2 = rng_uniform_f32(r);
   double lg = (double)ds_logf(u1, log_tab);
-  return __builtin_sqrt(-2.0 * lg) * ds_cos_0_2pi(6.283185307179586 * (double)u2, cos_tab);
+  return ds_sqrt_dev(-2.0 * lg) * ds_cos_0_2pi(6.283185307179586 * (double)u2, cos_tab);
 }
 
 /* simulations.py:23-36 */
@@ -82,7 +107,7 @@ DSD V3 cross3(const V3 &a, const V3 &b) {
 /* simulations.py:59-74: three divisions by the same length, evaluated with one
  * division + exact residual corrections (ds_div3, same quotients) */
 DSD void normalize3(V3 &v) {
-  double length = __builtin_sqrt(dot3(v, v));
+  double length = ds_sqrt_dev(dot3(v, v));
   ds_div3(&v.x, &v.y, &v.z, length);
 }
 
