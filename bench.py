@@ -131,8 +131,9 @@ def split_longest_edges(vertices, faces, n_target):
     return np.array(verts), out
 
 
-def make_workload(name, n_walkers):
-    """Returns dict(kind, gradient, dt, D, substrate, label, M, T)."""
+def make_workload(name, n_walkers, n_meas=1):
+    """Returns dict(kind, gradient, dt, D, substrate, label, M, T).  n_meas: measurements of the
+    C3-C5 waveform (M = 1 for the rate, M = 32 as the secondary figure)."""
     from disimpy_amd import gradients, substrates
 
     D = 2e-9
@@ -145,29 +146,29 @@ def make_workload(name, n_walkers):
         return dict(gradient=gradient, dt=dt, D=D, substrate=substrates.free(),
                     label="C1 free diffusion, %d spins x 100 steps, single-b PGSE" % n_walkers)
     if name == "c3":
-        gradient, dt = misst_waveform(10000, np.array([1e9]))
+        gradient, dt = misst_waveform(10000, np.linspace(1e9, 3e9, n_meas) if n_meas > 1 else np.array([1e9]))
         return dict(gradient=gradient, dt=dt, D=D, substrate=substrates.sphere(5e-6),
-                    label="C3 impermeable sphere r=5um, %d spins x 10000 steps, M=1" % n_walkers)
+                    label="C3 impermeable sphere r=5um, %d spins x 10000 steps, M=%d" % (n_walkers, n_meas))
     if name == "c4":
-        gradient, dt = misst_waveform(10000, np.array([1e9]))
+        gradient, dt = misst_waveform(10000, np.linspace(1e9, 3e9, n_meas) if n_meas > 1 else np.array([1e9]))
         v, f = packed_cylinders()
         sub = substrates.mesh(v, f, True, init_pos="uniform", quiet=True)
         return dict(gradient=gradient, dt=dt, D=D, substrate=sub,
-                    label="C4 packed cylinders (4096 tris, periodic), %d spins x 10000 steps, M=1" % n_walkers)
+                    label="C4 packed cylinders (4096 tris, periodic), %d spins x 10000 steps, M=%d" % (n_walkers, n_meas))
     if name == "c5":
-        gradient, dt = misst_waveform(10000, np.array([1e9]))
+        gradient, dt = misst_waveform(10000, np.linspace(1e9, 3e9, n_meas) if n_meas > 1 else np.array([1e9]))
         m = np.load(os.path.join(ROOT, "tests", "golden", "neuron_mesh.npz"))
         sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), True, init_pos="intra", quiet=True)
         return dict(gradient=gradient, dt=dt, D=D, substrate=sub,
-                    label="C5 neuron mesh (29688 tris, periodic, intra), %d spins x 10000 steps, M=1" % n_walkers)
+                    label="C5 neuron mesh (29688 tris, periodic, intra), %d spins x 10000 steps, M=%d" % (n_walkers, n_meas))
     if name == "c5b":
-        gradient, dt = misst_waveform(10000, np.array([1e9]))
+        gradient, dt = misst_waveform(10000, np.linspace(1e9, 3e9, n_meas) if n_meas > 1 else np.array([1e9]))
         m = np.load(os.path.join(ROOT, "tests", "golden", "neuron_mesh.npz"))
         v, f = split_longest_edges(m["vertices"], m["faces"], 50000)
         sub = substrates.mesh(v, f, True, init_pos="intra", quiet=True)
         return dict(gradient=gradient, dt=dt, D=D, substrate=sub,
                     label="C5b neuron mesh refined to %d tris (longest edges split), periodic, intra, %d spins x 10000 "
-                          "steps, M=1" % (len(f), n_walkers))
+                          "steps, M=%d" % (len(f), n_walkers, n_meas))
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -225,6 +226,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c5b"])
     ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (default: the config's)")
+    ap.add_argument("--measurements", type=int, default=1, help="C3-C5: number of b-values (M); C1/C2 are fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--tile-steps", type=int, default=0)
@@ -261,7 +263,7 @@ def main():
     default_walkers = {"c1": 1000, "c2": 1_000_000, "c3": 1_000_000, "c4": 1_000_000, "c5": 1_000_000, "c5b": 1_000_000}
     n_local = args.walkers or default_walkers[args.workload]
     n_total = n_local * world
-    w = make_workload(args.workload, n_local)
+    w = make_workload(args.workload, n_local, args.measurements)
     sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
     M, T = gradient.shape[0], gradient.shape[1]
     step_l = float(np.sqrt(6 * w["D"] * dt))
@@ -360,8 +362,9 @@ def main():
             "FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated: profiles/hbm_traffic.json)",
             "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "kernel": ("walk_kernel_coop4<%d>" % mb_pow2 if sub.type == "mesh" and mb_pow2 <= 2 and args.mesh_traversal != 1
-                       else "walk_kernel<%s,%d>" % (sub.type, mb_pow2)),
+            "kernel": ("walk_kernel<%s,%d>" % (sub.type, mb_pow2) if sub.type != "mesh" or args.mesh_traversal == 1
+                       else "walk_kernel_coop4<%d>" % mb_pow2 if mb_pow2 <= 2
+                       else "walk_kernel_coop4_traj + phase_from_traj_kernel<%d>" % mb_pow2),
             "algorithmic_bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch,
             "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms, "valu": valu,
             "note": "time-fused kernel: walker state stays in registers, so real HBM traffic (traffic) is far "

@@ -235,6 +235,8 @@ struct dsim_sim {
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
   bool sort_ready = false;
   double *phase_alt = nullptr;
+  double *traj = nullptr; /* [steps][3][n] positions of the last launch (mesh with M > 2: phases from positions) */
+  int traj_steps = 0;
   uint8_t *exc_alt = nullptr;
   int32_t *orig[2] = {nullptr, nullptr}, *perm = nullptr, *iota = nullptr;
   uint32_t *keys[2] = {nullptr, nullptr};
@@ -283,6 +285,7 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->sig_out) (void)hipFree(h->sig_out);
   if (h->staging) (void)hipFree(h->staging);
   if (h->phase_alt) (void)hipFree(h->phase_alt);
+  if (h->traj) (void)hipFree(h->traj);
   if (h->exc_alt) (void)hipFree(h->exc_alt);
   for (int b = 0; b < 2; b++) {
     if (h->orig[b]) (void)hipFree(h->orig[b]);
@@ -786,6 +789,7 @@ static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t ld
      * with the lane's own time index (32 or 64 bytes per step out of the L1), so there is no
      * LDS tile and no workgroup barrier in the time loop */
     auto k = MB <= COOP4_MAX_MB ? walk_kernel_coop4<(MB <= COOP4_MAX_MB ? MB : 1), 1> : walk_kernel<GEOM, MB, 0, GEOM == GEOM_MESH>;
+    if (MB == 1 && p.traj) k = walk_kernel_coop4_traj;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     k<<<grid, block, lds, s>>>(p);
@@ -898,8 +902,15 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   h->last_ms = 0;
   h->last_launches = 0;
   if (t_begin == t_end) return DSIM_OK;
-  const int mb = pick_mb(h->M, h->meas_per_pass);
-  const int passes = (h->M + mb - 1) / mb;
+  const int mb_all = pick_mb(h->M, h->meas_per_pass);
+  const int passes_all = (h->M + mb_all - 1) / mb_all;
+  /* Mesh, cooperative traversal, more than two measurements: the walk kernel carries no phase
+   * accumulators (it stays at 128 VGPRs / 4 waves per SIMD), records the positions of every
+   * step and phase_from_traj_kernel accumulates the phases from them - same operations, same
+   * order, no replay of the walk for M > 32. */
+  const bool split_phase = geom == GEOM_MESH && h->mesh_traversal != 1 && mb_all > COOP4_MAX_MB;
+  const int mb = split_phase ? 1 : mb_all;
+  const int passes = split_phase ? 1 : passes_all;
   p.n = h->n;
   p.g4 = h->g4;
   p.M = h->M;
@@ -949,15 +960,23 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
   }
+  if (split_phase && !h->traj) {
+    /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps */
+    int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, (int64_t)(32ull << 30) / (h->n * 24)));
+    HIP_TRY(hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)));
+    h->traj_steps = steps;
+  }
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   bool permuted = false;
-  for (int ta = t_begin; ta < t_end;) {
-    const int tb = resort > 0 ? std::min(t_end, ta + resort) : t_end;
+  for (int ca = t_begin; ca < t_end;) {
+    const int cb = resort > 0 ? std::min(t_end, ca + resort) : t_end;
     if (resort > 0) {
       int rc = resort_walkers(h, !permuted);
       if (rc) return rc;
       permuted = true;
     }
+   for (int ta = ca; ta < cb;) {
+    const int tb = split_phase ? std::min(cb, ta + h->traj_steps) : cb;
     const int src = h->cur, dst = passes > 1 ? 1 - h->cur : h->cur;
     p.x_in = h->x[src];
     p.y_in = h->y[src];
@@ -973,9 +992,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     p.exc = h->exc;
     p.t_begin = ta;
     p.t_end = tb;
+    p.traj = split_phase ? h->traj : nullptr;
     for (int pass = 0; pass < passes; pass++) {
       p.m0 = pass * mb;
-      p.mc = std::min(mb, h->M - p.m0);
+      p.mc = split_phase ? 0 : std::min(mb, h->M - p.m0);
       p.write_state = pass == passes - 1;
       hipError_t e;
       switch (geom) {
@@ -989,7 +1009,28 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       h->last_launches++;
     }
     h->cur = dst;
+    if (split_phase) {
+      const int tile_p = std::max(1, 16384 / (mb_all * 32));
+      const size_t lds_p = (size_t)tile_p * mb_all * 4 * sizeof(double);
+      const int grid_p = grid_for(h->n, 256);
+      for (int pass = 0; pass < passes_all; pass++) {
+        const int m0 = pass * mb_all, mc = std::min(mb_all, h->M - m0);
+#define DSIM_PHASE_LAUNCH(MBV)                                                                                             \
+  phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(h->traj, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \
+                                                                 p.gdt, h->phase)
+        switch (mb_all) {
+          case 4: DSIM_PHASE_LAUNCH(4); break;
+          case 8: DSIM_PHASE_LAUNCH(8); break;
+          case 16: DSIM_PHASE_LAUNCH(16); break;
+          default: DSIM_PHASE_LAUNCH(32); break;
+        }
+#undef DSIM_PHASE_LAUNCH
+        HIP_TRY(hipGetLastError());
+      }
+    }
     ta = tb;
+   }
+    ca = cb;
   }
   if (permuted) {
     int rc = restore_walker_order(h);

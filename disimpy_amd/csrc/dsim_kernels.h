@@ -100,6 +100,7 @@ struct WalkParams {
   int64_t max_iter;
   double eps, perm_prob;
   MeshDev mesh;
+  double *traj; /* walk_kernel_coop4_traj: [t - t_begin][3][n], the positions after every time step of the launch */
 };
 
 /* ---- one walker, one time step, by substrate -------------------------------- */
@@ -374,7 +375,7 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
 
 /* ---- the fused kernel --------------------------------------------------------- */
 
-template <int GEOM, int MB, int GSRC, int COOP>
+template <int GEOM, int MB, int GSRC, int COOP, int TRAJ = 0>
 DSD void walk_body(const WalkParams &p) {
   extern __shared__ double lds[];
   double *log_tab = lds;                           /* 128 doubles                     */
@@ -471,7 +472,13 @@ DSD void walk_body(const WalkParams &p) {
           r.x = __builtin_fma(step.x, sl, r.x);
           r.y = __builtin_fma(step.y, sl, r.y);
           r.z = __builtin_fma(step.z, sl, r.z);
-          if (GSRC == 0) {
+          if (TRAJ) {
+            double *q = p.traj + (int64_t)(t0 + k_lane - p.t_begin) * 3 * p.n + i;
+            q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
+          }
+          if (TRAJ) {
+            /* phases are accumulated from the recorded positions */
+          } else if (GSRC == 0) {
             const double *g = gt + k_lane * (MB * 4);
 #pragma unroll
             for (int m = 0; m < MB; m++) {
@@ -513,6 +520,10 @@ DSD void walk_body(const WalkParams &p) {
           step_ellipsoid(r, step, p.step_l, p, exc);
         } else {
           step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
+        }
+        if (TRAJ) {
+          double *q = p.traj + (int64_t)(t0 + k - p.t_begin) * 3 * p.n + i;
+          q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
         }
         /* phases[m, i] += GAMMA*dt*(gx*x + gy*y + gz*z), e.g. simulations.py:692-701 */
         if (GSRC == 0) {
@@ -565,6 +576,60 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
 template <int MB, int GSRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void walk_kernel_coop4(const WalkParams p) {
   walk_body<GEOM_MESH, MB, GSRC, 1>(p);
+}
+
+/* the same, recording the position after every step in p.traj (phases are then accumulated by
+ * phase_from_traj_kernel: mesh substrates with more than two measurements) */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void walk_kernel_coop4_traj(const WalkParams p) {
+  walk_body<GEOM_MESH, 1, 1, 1, 1>(p);
+}
+
+/* Phase accumulation from recorded positions: phases[m, i] += GAMMA*dt * g[m, t] . r_i(t) for the
+ * time steps of one launch, in the same order and with the same roundings as the fused kernels.
+ * Used for mesh substrates with more than two measurements: the cooperative walk kernel then
+ * carries no phase accumulators at all (128 VGPRs, 4 waves/SIMD whatever M is), writes 24 bytes
+ * per walker and step, and this kernel - pure streaming + FMAs, a few per cent of the walk's
+ * time - does the rest.  traj = [step][3][n]; the gradient tile lives in LDS as in walk_body. */
+template <int MB>
+__global__ __launch_bounds__(256) void phase_from_traj_kernel(const double *traj, int64_t n, int steps, int tile_steps, const double *g4,
+                                                              int M, int m0, int mc, int t_first, double gdt, double *phase) {
+  extern __shared__ double gt[];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  double ph[MB];
+#pragma unroll
+  for (int m = 0; m < MB; m++) ph[m] = (live && m < mc) ? phase[(int64_t)(m0 + m) * n + i] : 0.0;
+  for (int t0 = 0; t0 < steps; t0 += tile_steps) {
+    const int kt = min(tile_steps, steps - t0);
+    __syncthreads();
+    const int row = mc * 2;
+    const double2 *src = reinterpret_cast<const double2 *>(g4);
+    double2 *dst = reinterpret_cast<double2 *>(gt);
+    for (int e = threadIdx.x; e < kt * (MB * 2); e += blockDim.x) {
+      int k = e / (MB * 2), c = e - k * (MB * 2);
+      dst[e] = c < row ? src[((int64_t)(t_first + t0 + k) * M + m0) * 2 + c] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    if (live) {
+      for (int k = 0; k < kt; k++) {
+        const double *q = traj + (int64_t)(t0 + k) * 3 * n + i;
+        const double x = q[0], y = q[n], z = q[2 * n];
+        const double *g = gt + k * (MB * 4);
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+          double2 gxy = *reinterpret_cast<const double2 *>(g + m * 4);
+          double gz = g[m * 4 + 2];
+          double inner = __builtin_fma(gz, z, __builtin_fma(gxy.x, x, gxy.y * y));
+          ph[m] = __builtin_fma(gdt, inner, ph[m]);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+      if (m < mc) phase[(int64_t)(m0 + m) * n + i] = ph[m];
+  }
 }
 
 /* ---- signal: sum over walkers of cos/sin(phase), wavefront shuffles ----------- */

@@ -326,6 +326,28 @@ def test_mesh_spatial_resorting_is_invisible(lib, oracle_exact, resort_steps, tr
     _assert_identical(gpu, ref)
 
 
+@pytest.mark.parametrize("M", [5, 32, 40])
+def test_mesh_many_measurements_phases_from_recorded_positions(lib, oracle_exact, M):
+    """More than two measurements on a mesh: the cooperative walk kernel records the positions of
+    every step and a second kernel accumulates the phases from them (M = 40: two passes of that
+    kernel, no replay of the walk).  Same operations in the same order: bit-identical phases."""
+    from disimpy_amd import substrates
+
+    m = golden("cylinder_mesh_closed.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.array([1e-6, 1e-6, 0.0]),
+                          n_sv=np.array([6, 6, 12]), quiet=True)
+    n, T, dt = 4500, 50, 5e-4
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(M, T)
+    pos0 = np.random.RandomState(28).random_sample((n, 3)) * sub.voxel_size
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 15, kw, mesh=ma)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 15, kw, mesh=ma, tuning=dict(resort_steps=9, mesh_traversal=2),
+                   chunks=[0, 21, 50])
+    _assert_identical(gpu, ref)
+
+
 def test_mesh_huge_steps_fall_back_to_serial_scans(lib, oracle_exact):
     """Steps several voxels long (more than 256 subvoxels in range, periodic images): the
     cooperative traversal hands such walkers to the serial path; results stay identical."""
