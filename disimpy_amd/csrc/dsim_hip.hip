@@ -799,6 +799,9 @@ static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t ld
       walk_kernel<GEOM, MB, 1, 0><<<grid, block, lds, s>>>(p);
     else
 #endif
+        if (MB == 32 && p.traj)
+      walk_kernel_traj32<GEOM><<<grid, block, lds, s>>>(p);
+    else
       walk_kernel<GEOM, MB, 0, 0><<<grid, block, lds, s>>>(p);
   }
   (void)gsrc;
@@ -909,8 +912,13 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
    * step and phase_from_traj_kernel accumulates the phases from them - same operations, same
    * order, no replay of the walk for M > 32. */
   const bool split_phase = geom == GEOM_MESH && h->mesh_traversal != 1 && mb_all > COOP4_MAX_MB;
+  /* Everything else with more than 32 measurements: the first 32 in the walk kernel, which also
+   * records the positions; the other passes accumulate from the positions (128 FMAs per walker
+   * and step) instead of replaying RNG and geometry (480). */
+  const bool record_extra = !split_phase && passes_all > 1 && mb_all == 32 && h->grad_src == 0;
+  const bool record = split_phase || record_extra;
   const int mb = split_phase ? 1 : mb_all;
-  const int passes = split_phase ? 1 : passes_all;
+  const int passes = record ? 1 : passes_all;
   p.n = h->n;
   p.g4 = h->g4;
   p.M = h->M;
@@ -960,7 +968,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
   }
-  if (split_phase && !h->traj) {
+  if (record && !h->traj) {
     /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps */
     int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, (int64_t)(32ull << 30) / (h->n * 24)));
     HIP_TRY(hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)));
@@ -976,7 +984,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       permuted = true;
     }
    for (int ta = ca; ta < cb;) {
-    const int tb = split_phase ? std::min(cb, ta + h->traj_steps) : cb;
+    const int tb = record ? std::min(cb, ta + h->traj_steps) : cb;
     const int src = h->cur, dst = passes > 1 ? 1 - h->cur : h->cur;
     p.x_in = h->x[src];
     p.y_in = h->y[src];
@@ -992,7 +1000,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     p.exc = h->exc;
     p.t_begin = ta;
     p.t_end = tb;
-    p.traj = split_phase ? h->traj : nullptr;
+    p.traj = record ? h->traj : nullptr;
     for (int pass = 0; pass < passes; pass++) {
       p.m0 = pass * mb;
       p.mc = split_phase ? 0 : std::min(mb, h->M - p.m0);
@@ -1009,11 +1017,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       h->last_launches++;
     }
     h->cur = dst;
-    if (split_phase) {
+    if (record) {
       const int tile_p = std::max(1, 16384 / (mb_all * 32));
       const size_t lds_p = (size_t)tile_p * mb_all * 4 * sizeof(double);
       const int grid_p = grid_for(h->n, 256);
-      for (int pass = 0; pass < passes_all; pass++) {
+      for (int pass = split_phase ? 0 : 1; pass < passes_all; pass++) {
         const int m0 = pass * mb_all, mc = std::min(mb_all, h->M - m0);
 #define DSIM_PHASE_LAUNCH(MBV)                                                                                             \
   phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(h->traj, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \

@@ -578,6 +578,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   walk_body<GEOM_MESH, MB, GSRC, 1>(p);
 }
 
+/* 32 measurements in the kernel and the positions of every step recorded in p.traj: the first pass
+ * of a run with M > 32; the other measurements are accumulated by phase_from_traj_kernel instead
+ * of replaying the walk */
+template <int GEOM>
+__global__ __launch_bounds__(256) void walk_kernel_traj32(const WalkParams p) {
+  walk_body<GEOM, 32, 0, 0, 1>(p);
+}
+
 /* the same, recording the position after every step in p.traj (phases are then accumulated by
  * phase_from_traj_kernel: mesh substrates with more than two measurements) */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void walk_kernel_coop4_traj(const WalkParams p) {
