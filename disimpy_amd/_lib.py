@@ -18,7 +18,7 @@ SYMBOLS = (
     "dsim_run_free", "dsim_run_sphere", "dsim_run_cylinder", "dsim_run_ellipsoid", "dsim_run_mesh",
     "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
-    "dsim_last_run_ms", "dsim_set_tuning",
+    "dsim_last_run_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -74,6 +74,8 @@ def load():
     lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
     lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
     lib.dsim_set_tuning.argtypes = [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.dsim_set_recording.argtypes = [_h, C.c_int32]
+    lib.dsim_get_recorded.argtypes = [_h, C.c_int32, C.c_int32, _f64p]
     _lib = lib
     return lib
 
@@ -221,6 +223,16 @@ class Sim:
 
     def run_mesh(self, max_iter, epsilon, perm_prob, t0, t1):
         check(self._lib.dsim_run_mesh(self._h, max_iter, epsilon, float(perm_prob), t0, t1))
+
+    def set_recording(self, enable=True):
+        """Keep the positions after every step of the following run_* calls on the device."""
+        check(self._lib.dsim_set_recording(self._h, 1 if enable else 0))
+
+    def recorded(self, t0, t1):
+        """(t1 - t0, n, 3) positions after steps t0 .. t1-1 of the last (recorded) run_* call."""
+        out = np.empty((t1 - t0, 3, self.n), dtype=np.float64)
+        check(self._lib.dsim_get_recorded(self._h, t0, t1, p_f64(out)))
+        return np.ascontiguousarray(out.transpose(0, 2, 1))
 
     def last_run_ms(self):
         ms, nl = C.c_double(0), C.c_int32(0)

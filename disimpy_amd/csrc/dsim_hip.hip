@@ -237,6 +237,8 @@ struct dsim_sim {
   double *phase_alt = nullptr;
   double *traj = nullptr; /* [steps][3][n] positions of the last launch (mesh with M > 2: phases from positions) */
   int traj_steps = 0;
+  bool recording = false;        /* dsim_set_recording: keep the positions of every step of a run */
+  int rec_t0 = 0, rec_t1 = 0;    /* time range held in traj after a recorded run */
   uint8_t *exc_alt = nullptr;
   int32_t *orig[2] = {nullptr, nullptr}, *perm = nullptr, *iota = nullptr;
   uint32_t *keys[2] = {nullptr, nullptr};
@@ -911,13 +913,16 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
    * accumulators (it stays at 128 VGPRs / 4 waves per SIMD), records the positions of every
    * step and phase_from_traj_kernel accumulates the phases from them - same operations, same
    * order, no replay of the walk for M > 32. */
-  const bool split_phase = geom == GEOM_MESH && h->mesh_traversal != 1 && mb_all > COOP4_MAX_MB;
+  const bool split_phase = geom == GEOM_MESH && h->mesh_traversal != 1 && (mb_all > COOP4_MAX_MB || h->recording);
   /* Everything else with more than 32 measurements: the first 32 in the walk kernel, which also
    * records the positions; the other passes accumulate from the positions (128 FMAs per walker
    * and step) instead of replaying RNG and geometry (480). */
-  const bool record_extra = !split_phase && passes_all > 1 && mb_all == 32 && h->grad_src == 0;
+  if (h->recording && h->grad_src != 0) return fail(DSIM_ERR_STATE, "recording needs the LDS gradient path (gradient_source 1)");
+  const bool record_extra = !split_phase && (h->recording || (passes_all > 1 && mb_all == 32)) && h->grad_src == 0;
   const bool record = split_phase || record_extra;
-  const int mb = split_phase ? 1 : mb_all;
+  /* a recording run carries up to 32 measurements in the 32-accumulator kernel (the only one with a
+   * recording variant) */
+  const int mb = split_phase ? 1 : (record_extra ? 32 : mb_all);
   const int passes = record ? 1 : passes_all;
   p.n = h->n;
   p.g4 = h->g4;
@@ -953,7 +958,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   if (geom == GEOM_MESH) grid = (grid + 255) & ~255; /* XCD-aware group mapping in the kernel */
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
   int resort = 0;
-  if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX) {
+  if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX && !h->recording) {
     resort = h->resort_steps;
     if (resort == 0) {
       double hmin = 1e300;
@@ -968,11 +973,24 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
   }
-  if (record && !h->traj) {
-    /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps */
-    int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, (int64_t)(32ull << 30) / (h->n * 24)));
-    HIP_TRY(hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)));
-    h->traj_steps = steps;
+  h->rec_t0 = h->rec_t1 = 0;
+  if (record) {
+    /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps
+     * per launch; a recording run must hold its whole range */
+    const int64_t fit = (int64_t)(32ull << 30) / (h->n * 24);
+    int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, fit));
+    if (h->recording) {
+      if (t_end - t_begin > fit) return fail(DSIM_ERR_INVALID, "recording: %d steps of %lld walkers do not fit 32 GB", t_end - t_begin, (long long)h->n);
+      steps = std::max(steps, t_end - t_begin);
+    }
+    if (h->traj && h->traj_steps < steps) {
+      HIP_TRY(hipFree(h->traj));
+      h->traj = nullptr;
+    }
+    if (!h->traj) {
+      HIP_TRY(hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)));
+      h->traj_steps = steps;
+    }
   }
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   bool permuted = false;
@@ -984,7 +1002,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       permuted = true;
     }
    for (int ta = ca; ta < cb;) {
-    const int tb = record ? std::min(cb, ta + h->traj_steps) : cb;
+    const int tb = record ? std::min(cb, ta + h->traj_steps) : cb; /* recording: traj_steps covers the whole range */
     const int src = h->cur, dst = passes > 1 ? 1 - h->cur : h->cur;
     p.x_in = h->x[src];
     p.y_in = h->y[src];
@@ -1027,6 +1045,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(h->traj, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \
                                                                  p.gdt, h->phase)
         switch (mb_all) {
+          case 1: DSIM_PHASE_LAUNCH(1); break;
+          case 2: DSIM_PHASE_LAUNCH(2); break;
           case 4: DSIM_PHASE_LAUNCH(4); break;
           case 8: DSIM_PHASE_LAUNCH(8); break;
           case 16: DSIM_PHASE_LAUNCH(16); break;
@@ -1043,6 +1063,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   if (permuted) {
     int rc = restore_walker_order(h);
     if (rc) return rc;
+  }
+  if (h->recording) {
+    h->rec_t0 = t_begin;
+    h->rec_t1 = t_end;
   }
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1078,6 +1102,33 @@ extern "C" int dsim_debug_timers(unsigned long long *out16) {
   return DSIM_OK;
 }
 #endif
+
+extern "C" int dsim_set_recording(dsim_handle h, int32_t enable) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  h->recording = enable != 0;
+  h->rec_t0 = h->rec_t1 = 0;
+  if (!h->recording && h->traj) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(h->traj));
+    h->traj = nullptr;
+    h->traj_steps = 0;
+  }
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_recorded(dsim_handle h, int32_t t_begin, int32_t t_end, double *out) {
+  if (!h || !out) return fail(DSIM_ERR_INVALID, "dsim_get_recorded: null argument");
+  if (!h->recording || !h->traj) return fail(DSIM_ERR_STATE, "dsim_get_recorded: recording is off");
+  if (t_begin < h->rec_t0 || t_end > h->rec_t1 || t_begin > t_end)
+    return fail(DSIM_ERR_INVALID, "dsim_get_recorded: [%d, %d) outside the recorded range [%d, %d)", t_begin, t_end, h->rec_t0, h->rec_t1);
+  HIP_TRY(hipSetDevice(h->device));
+  if (t_begin == t_end) return DSIM_OK;
+  const size_t row = (size_t)3 * h->n * sizeof(double);
+  HIP_TRY(hipMemcpyAsync(out, h->traj + (size_t)(t_begin - h->rec_t0) * 3 * h->n, (size_t)(t_end - t_begin) * row, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return DSIM_OK;
+}
 
 extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");

@@ -261,7 +261,10 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         if traj:
             _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions[a:b]))
         if traj:
-            chunk = 1  # the trajectories file needs the positions after every step
+            # the trajectories file needs the positions after every step: the device records them
+            # and hands them over once per range of steps (<= 64 MB) instead of once per step
+            sim.set_recording(True)
+            chunk = max(1, min(n_t, (64 << 20) // (24 * max(1, b - a))))
         elif quiet:
             chunk = n_t
         else:
@@ -272,7 +275,8 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1)
             ms_total += sim.last_run_ms()[0]
             if traj:
-                _write_traj(traj, "a", sim.positions())
+                for step_positions in sim.recorded(t0, t1):
+                    _write_traj(traj, "a", step_positions)
             if not quiet:
                 sys.stdout.write(f"\r{np.round((t0 / n_t) * 100, 1)}%")
                 sys.stdout.flush()

@@ -145,6 +145,16 @@ int dsim_interval_sv_overlap(const double *xs, int64_t n_xs, double x1, double x
  * kernel launches it made, and the name of the kernel. */
 int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
 
+/* Trajectories (replaces the reference's per-step `positions.copy_to_host()` + file append of
+ * simulations.py:1043-1048, :1211-1213 by one transfer per range of steps).
+ * dsim_set_recording(h, 1): every following dsim_run_* call keeps the position of every walker
+ * after every time step of its range in device memory (24 bytes per walker and step; the call
+ * fails if the range does not fit in 32 GB); 0 switches it off and frees the buffer.
+ * dsim_get_recorded copies steps [t_begin, t_end) of the LAST dsim_run_* call to the host,
+ * component-major: out[((t - t_begin) * 3 + c) * n + i]. */
+int dsim_set_recording(dsim_handle h, int32_t enable);
+int dsim_get_recorded(dsim_handle h, int32_t t_begin, int32_t t_end, double *out);
+
 /* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
  * LDS gradient tile, measurements held in registers per pass, and - for mesh
  * substrates - the number of time steps between spatial re-sorts of the walker

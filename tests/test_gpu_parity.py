@@ -348,6 +348,66 @@ def test_mesh_many_measurements_phases_from_recorded_positions(lib, oracle_exact
     _assert_identical(gpu, ref)
 
 
+@pytest.mark.parametrize("kind,M", [("free", 1), ("free", 40), ("sphere", 3), ("mesh", 1), ("mesh", 5)])
+def test_recorded_trajectories_equal_step_by_step_positions(lib, kind, M):
+    """dsim_set_recording: the positions after every step of a run, fetched once per range, are
+    the positions a step-by-step run reports, and recording does not change phases or state."""
+    from disimpy_amd import substrates
+
+    n, T, dt = 5000, 30, 5e-4
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(M, T)
+    sub = None
+    if kind == "mesh":
+        m = golden("cylinder_mesh_closed.npz")
+        sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.array([1e-6, 1e-6, 0.0]),
+                              n_sv=np.array([6, 6, 12]), quiet=True)
+    pos0 = None
+    if kind == "mesh":
+        pos0 = np.random.RandomState(4).random_sample((n, 3)) * sub.voxel_size
+    elif kind == "sphere":
+        pos0 = (np.random.RandomState(4).random_sample((n, 3)) - 0.5) * 2e-6
+
+    def run(sim, t0, t1):
+        if kind == "free":
+            sim.run_free(t0, t1)
+        elif kind == "sphere":
+            sim.run_sphere(2e-6, 1000, 1e-13, t0, t1)
+        else:
+            sim.run_mesh(1000, 1e-13, 0.0, t0, t1)
+
+    def make():
+        sim = lib.Sim(n, g, dt, step_l)
+        sim.rng_init_device(77)
+        if pos0 is not None:
+            sim.set_positions(pos0)
+        if sub is not None:
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices,
+                         sub.triangle_indices)
+        return sim
+
+    with make() as sim:  # step by step, no recording
+        steps = []
+        for t in range(T):
+            run(sim, t, t + 1)
+            steps.append(sim.positions())
+        ref_phases, ref_states = sim.phases(), sim.rng_states()
+    with make() as sim:  # two recorded ranges
+        sim.set_recording(True)
+        run(sim, 0, 17)
+        rec = [sim.recorded(0, 5), sim.recorded(5, 17)]
+        run(sim, 17, T)
+        rec.append(sim.recorded(17, T))
+        with pytest.raises(lib.DsimError):
+            sim.recorded(0, 5)  # only the last run is held
+        phases, states = sim.phases(), sim.rng_states()
+        sim.set_recording(False)
+    rec = np.concatenate(rec, axis=0)
+    assert rec.shape == (T, n, 3)
+    assert np.array_equal(rec, np.stack(steps))
+    assert np.array_equal(phases, ref_phases) and np.array_equal(states, ref_states)
+
+
 def test_mesh_huge_steps_fall_back_to_serial_scans(lib, oracle_exact):
     """Steps several voxels long (more than 256 subvoxels in range, periodic images): the
     cooperative traversal hands such walkers to the serial path; results stay identical."""
