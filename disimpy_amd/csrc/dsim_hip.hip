@@ -987,9 +987,16 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       HIP_TRY(hipFree(h->traj));
       h->traj = nullptr;
     }
-    if (!h->traj) {
-      HIP_TRY(hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)));
-      h->traj_steps = steps;
+    while (!h->traj) {
+      /* not a recording run: shorter launches if the device cannot spare that much memory */
+      if (hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)) == hipSuccess) {
+        h->traj_steps = steps;
+        break;
+      }
+      h->traj = nullptr;
+      (void)hipGetLastError();
+      if (h->recording || steps <= 16) return fail(DSIM_ERR_HIP, "no device memory for %d steps of recorded positions", steps);
+      steps = std::max(16, steps / 2);
     }
   }
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
