@@ -979,6 +979,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
      * per launch; a recording run must hold its whole range */
     const int64_t fit = (int64_t)(32ull << 30) / (h->n * 24);
     int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, fit));
+    steps = std::min(steps, std::max(16, t_end - t_begin)); /* no more than this run needs */
     if (h->recording) {
       if (t_end - t_begin > fit) return fail(DSIM_ERR_INVALID, "recording: %d steps of %lld walkers do not fit 32 GB", t_end - t_begin, (long long)h->n);
       steps = std::max(steps, t_end - t_begin);
