@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c5b"])
     ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (default: the config's)")
     ap.add_argument("--measurements", type=int, default=1, help="C3-C5: number of b-values (M); C1/C2 are fixed")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only for testing the "
+                         "multi-rank path with several ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--tile-steps", type=int, default=0)
@@ -256,9 +259,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if world > 1 else 0
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # testing aid: several ranks may share one GPU (RCCL refuses that), the reduction goes over gloo
+            dist.init_process_group("gloo")
+    n_dev = max(1, _lib.device_count())
+    device = (local_rank if args.backend == "nccl" else local_rank % n_dev) if world > 1 else 0
 
     default_walkers = {"c1": 1000, "c2": 1_000_000, "c3": 1_000_000, "c4": 1_000_000, "c5": 1_000_000, "c5b": 1_000_000}
     n_local = args.walkers or default_walkers[args.workload]
@@ -319,7 +327,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
