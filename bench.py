@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: spin-steps/s of the fused random-walk kernels.
+"""Headline benchmark: spin-steps/s of the fused random-walk kernels on the north-star workload.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5|c5b]
+    python bench.py --gpus N --steps K --warmup W [--workload c5b|c5|c4|c3|c2|c1]
 
-One "step" = one pass of the hot path over one batch: every walker of this
-rank's shard is advanced through the whole gradient waveform (T time steps, one
-fused kernel launch per block of <= 32 measurements), the signal is reduced on
-the device and - for N > 1 - all-reduced over RCCL.  Default workload = BASELINE
-config C2: free diffusion, 1e6 spins x 1e3 steps, 32-direction PGSE.  Walker
-shards are weak-scaled: each rank owns 1e6 walkers with global indices
-[rank*1e6, (rank+1)*1e6), so RNG states and results are partition-independent.
-Inputs (gradient tiles, walker state, mesh index) are resident in HBM before
-the timed region; successive steps continue the same walk.
+Default workload = BASELINE config C5 as the north star states it: the neuron mesh refined to
+50 000 triangles (C5b), periodic, walkers inside the neuron, 1e7 spins x 1e4 steps, M = 1.
+The job is STRONG-scaled: the 1e7 walkers are split over the N ranks (walker i keeps RNG state i
+and initial position i, so the result does not depend on N), one rank per GPU.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` is the ALGORITHMIC byte
-rate (80 + 16 M bytes per spin-step, the state the reference's
-step-synchronous kernels round-trip through HBM) over the kernel time measured
-with HIP events on the library's stream; `roofline.traffic` is the HBM traffic
-measured with rocprofv3 PMC counters (profiles/), far below it because the
-fused kernel keeps walker state in registers.
+One "step" = one pass of the hot path over one batch: every walker of this rank's shard is
+advanced through the whole gradient waveform (T time steps, one fused launch per re-sort
+interval), the signal is reduced on the device and - for N > 1 - all-reduced over RCCL.
+Inputs (gradient, walker state, mesh index) are resident in HBM before the timed region;
+successive steps continue the same walk.
+
+`--gpus N` without WORLD_SIZE in the environment makes this process a launcher: it starts N
+fresh rank processes itself (before anything touches the GPU), forwards rank 0's JSON line and
+exits non-zero if any rank fails.  Under `python -m torch.distributed.run` it is a rank.
+
+Prints ONE JSON line (rank 0).  The walk kernel keeps all walker state in registers, so HBM is
+not what bounds it; `roofline` therefore reports the bound that holds - vector-ALU issue:
+`achieved` = VALU wave-instructions per second (instructions per wavefront-step from the
+rocprofv3 SQ_INSTS_VALU count of the same kernel in profiles/, times the wavefront-steps per
+second measured in THIS run with HIP events around the kernel on the library's stream) over
+`peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  The algorithmic-HBM figure
+of SURVEY.md 8d is kept in `roofline.algorithmic_hbm` with its caveat.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 4.0  # 256 CUs x 4 SIMDs; one wave64 VALU instruction per 4 cycles
+VALU_PEAK = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU  # wave-instructions per second
+
+DEFAULT_TOTAL_WALKERS = {"c1": 1000, "c2": 1_000_000, "c3": 1_000_000, "c4": 10_000_000, "c5": 10_000_000,
+                         "c5b": 10_000_000}  # BASELINE.json configs
 
 
 def fib_dirs(n):
@@ -172,36 +185,42 @@ def make_workload(name, n_walkers, n_meas=1):
     raise SystemExit("unknown workload %r" % name)
 
 
-def cpu_baseline(w, budget_s=15.0):
+def oracle_geometry(o, sub):
+    """Geometry descriptor of the CPU oracle for a substrate (test infrastructure, never the product path)."""
+    from oracle.oracle import FREE, MESH, SPHERE
+
+    if sub.type == "free":
+        return o.geom(FREE)
+    if sub.type == "sphere":
+        return o.geom(SPHERE, radius=sub.radius)
+    ma = dict(vertices=sub.vertices, faces=sub.faces, xs=sub.xs, ys=sub.ys, zs=sub.zs,
+              subvoxel_indices=sub.subvoxel_indices, triangle_indices=sub.triangle_indices, n_sv=sub.n_sv)
+    return o.geom(MESH, mesh=ma)
+
+
+def sample_positions(sub, n, positions):
+    """Initial positions of walkers [0, n) for the CPU legs: the rows the GPU run uses."""
+    if sub.type == "free":
+        return np.zeros((n, 3))
+    reps = -(-n // len(positions))
+    return np.ascontiguousarray(np.tile(positions, (reps, 1))[:n])
+
+
+def cpu_baseline(w, positions, budget_s=15.0):
     """The CPU oracle (a port of the reference's algorithm: oracle/dsim_oracle.c) on a
     bounded sample of the SAME workload, all host cores (OpenMP) and one core."""
-    from disimpy_amd import simulations
-    from oracle.oracle import CYLINDER, ELLIPSOID, FREE, MESH, SPHERE, Oracle  # noqa: F401
+    from oracle.oracle import Oracle
 
     o = Oracle(exact=False)
     sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
     step_l = float(np.sqrt(6 * w["D"] * dt))
     T = gradient.shape[1]
     cores = os.cpu_count() or 1
-
-    def geom_and_pos(n):
-        if sub.type == "free":
-            return o.geom(FREE), np.zeros((n, 3))
-        if sub.type == "sphere":
-            return o.geom(SPHERE, radius=sub.radius), simulations._fill_sphere(n, sub.radius, simulations._host_rng(123))
-        ma = dict(vertices=sub.vertices, faces=sub.faces, xs=sub.xs, ys=sub.ys, zs=sub.zs,
-                  subvoxel_indices=sub.subvoxel_indices, triangle_indices=sub.triangle_indices, n_sv=sub.n_sv)
-        g = o.geom(MESH, mesh=ma)
-        if isinstance(sub.init_pos, str) and sub.init_pos == "intra":
-            pos = o.fill_mesh(n, g, sub.voxel_size, True, 123)
-        else:
-            pos = np.random.RandomState(123).random_sample((n, 3)) * sub.voxel_size
-        return g, pos
+    g = oracle_geometry(o, sub)
 
     def timed(n, threads):
-        g, pos = geom_and_pos(n)
+        pos = sample_positions(sub, n, positions)
         st = o.rng_states(n, 123)
-        pos = np.ascontiguousarray(pos)
         t0 = time.perf_counter()
         o.run(g, gradient, dt, step_l, pos, st, n_threads=threads)
         return n * T / (time.perf_counter() - t0)
@@ -219,38 +238,206 @@ def cpu_baseline(w, budget_s=15.0):
     }  # fmt: skip
 
 
-def main():
+def signal_rel_err(w, positions, device, n=2048):
+    """Second half of BASELINE.json's metric: the signal of the first n walkers (same seed, same
+    initial positions) on the GPU against the CPU oracle, outside the timed region.  `exact`
+    = the oracle build that shares the library's log/cos (bit-identical walk expected: the
+    difference is summation order only); `glibc` = the build pinned to the reference's golden
+    trajectory (chaotic geometries decorrelate walker by walker, so this one is statistical)."""
+    from disimpy_amd import _lib, simulations
+    from oracle.oracle import Oracle
+
+    sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
+    step_l = float(np.sqrt(6 * w["D"] * dt))
+    T = gradient.shape[1]
+    pos0 = sample_positions(sub, n, positions)
+    with _lib.Sim(n, gradient, dt, step_l, device=device, first_walker=0) as sim:
+        sim.rng_init_device(123)
+        if sub.type != "free":
+            sim.set_positions(pos0)
+        if sub.type == "mesh":
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices,
+                         sub.triangle_indices)
+        simulations._run_range(sim, sub, w["frames"], 1000, 1e-13, 0, T)
+        c_gpu, _, _ = sim.signal()
+        ph_gpu = sim.phases()
+    out = {"walkers": n, "steps": T}
+    for name, exact in (("exact", True), ("glibc", False)):
+        o = Oracle(exact=exact)
+        p = pos0.copy()
+        ph, exc, _ = o.run(oracle_geometry(o, sub), gradient, dt, step_l, p, o.rng_states(n, 123),
+                           n_threads=os.cpu_count() or 1)
+        c, _ = o.signal(ph, exc)
+        out[name] = float(np.max(np.abs(c_gpu - c) / np.maximum(np.abs(c), 1e-300)))
+        if exact:
+            out["phases_identical"] = bool(np.array_equal(ph, ph_gpu))
+    return out
+
+
+def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
+    """n_steps passes over the waveform; returns (elapsed s, walk-kernel ms per step, launches, last signal)."""
+    from disimpy_amd import sharding, simulations
+
+    walk_ms, run_ms, launches = [], [], []
+    sig = None
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        if sim is not None:
+            simulations._run_range(sim, sub, frames, 1000, 1e-13, 0, T)
+            run_ms.append(sim.last_run_ms()[0])
+            ms, nl = sim.last_walk_ms()
+            walk_ms.append(ms)
+            launches.append(nl)
+            c, s, nexc = sim.signal()
+        else:  # a rank without walkers still takes part in the collective
+            c, s, nexc = np.zeros(M), np.zeros(M), 0
+        sig = sharding.reduce_signal(c, s, nexc, dist, device)
+    fence()
+    return time.perf_counter() - t0, walk_ms, run_ms, launches, sig
+
+
+def setup_sim(args, w, n_total, a, b, device):
+    """Untimed set-up: everything resident in HBM.  Returns (sim, positions of [a, b), setup_s)."""
+    from disimpy_amd import _lib, simulations
+
+    sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
+    step_l = float(np.sqrt(6 * w["D"] * dt))
+    setup = {}
+    t = time.perf_counter()
+    np.random.seed(123)
+    positions, frames = simulations._initial_positions(n_total, sub, 123, True, device, (a, b))
+    w["frames"] = frames
+    setup["initial_positions"] = time.perf_counter() - t
+    if b == a:
+        return None, positions, setup
+    t = time.perf_counter()
+    sim = _lib.Sim(b - a, gradient, dt, step_l, device=device, first_walker=a)
+    sim.set_tuning(args.block_size, args.tile_steps, args.meas_per_pass, args.resort_steps, args.gradient_source,
+                   args.mesh_traversal)
+    setup["create"] = time.perf_counter() - t
+    t = time.perf_counter()
+    sim.rng_init_device(123)
+    setup["rng_init_device"] = time.perf_counter() - t
+    t = time.perf_counter()
+    if positions is not None:
+        sim.set_positions(np.ascontiguousarray(positions, dtype=np.float64))
+    setup["upload_positions"] = time.perf_counter() - t
+    t = time.perf_counter()
+    if sub.type == "mesh":
+        sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices,
+                     sub.triangle_indices)
+    setup["mesh_index_upload"] = time.perf_counter() - t
+    return sim, positions, setup
+
+
+def kernel_name(sub, M, args):
+    mb = 1 << max(0, (min(M, 32) - 1).bit_length())
+    if sub.type != "mesh" or args.mesh_traversal == 1:
+        return "walk_kernel<%s,%d>" % (sub.type, mb)
+    return "walk_kernel_coop4<%d>" % mb if mb <= 2 else "walk_kernel_coop4_traj + phase_from_traj_kernel<%d>" % mb
+
+
+def profile_entry(workload):
+    """Counter figures of the dominant kernel for this workload (profiles/kernel_counters.json, written from
+    the rocprofv3 --pmc summaries committed beside it)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "kernel_counters.json"))).get(workload)
+    except Exception:
+        return None
+
+
+def secondary_rates(args, device):
+    """The other BASELINE configs at a glance (rank 0 of a single-GPU run, after the timed region):
+    C2 and C3 at their full sizes, C4 with 1e6 of its 1e7 walkers."""
+    out = {}
+    for name, n, meas in (("c2", 1_000_000, 1), ("c3", 1_000_000, 1), ("c4", 1_000_000, 1)):
+        w = make_workload(name, n, meas)
+        sub, T = w["substrate"], w["gradient"].shape[1]
+        sim, _, _ = setup_sim(args, w, n, 0, n, device)
+        run_steps(sim, sub, w["frames"], T, 1, None, device, lambda: None)
+        el, walk_ms, _, _, sig = run_steps(sim, sub, w["frames"], T, 2, None, device, lambda: None)
+        sim.close()
+        out[name] = {"workload": w["label"], "value": n * T * 2 / el, "unit": "spin-steps/s",
+                     "walk_kernel_spin_steps_per_s": n * T / (float(np.mean(walk_ms)) * 1e-3)}
+    return out
+
+
+def launch_ranks(n_ranks, argv, script=None):
+    """`--gpus N` outside a process group: start the N ranks ourselves.  Nothing in this process has
+    touched HIP or torch.cuda (no exec of a GPU-initialised process either: plain children).
+    Rank r gets RANK = LOCAL_RANK = r, WORLD_SIZE = N and a free rendezvous port on 127.0.0.1;
+    rank 0's stdout (the JSON line) is forwarded; any failing rank ends the job with a non-zero exit."""
+    script = script or os.path.abspath(__file__)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    failed = None
+    deadline = time.time() + 3600
+    pending = set(range(len(procs)))
+    while pending and time.time() < deadline:
+        for r in list(pending):
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0 and failed is None:
+                    failed = (r, rc)
+        if failed is not None:
+            break
+        time.sleep(0.1)
+    if failed is not None or pending:
+        for r in pending:  # our own children, by PID
+            procs[r].kill()
+        for pr in procs:
+            pr.wait()
+        sys.stdout.write(out0)
+        raise SystemExit("rank %s failed (exit code %s)" % (failed or ("?", "timeout")))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c5b"])
-    ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (default: the config's)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c5b", choices=["c1", "c2", "c3", "c4", "c5", "c5b"])
+    ap.add_argument("--walkers", type=int, default=0, help="TOTAL walkers over all GPUs (default: the config's)")
     ap.add_argument("--measurements", type=int, default=1, help="C3-C5: number of b-values (M); C1/C2 are fixed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only for testing the "
                          "multi-rank path with several ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2/C3/C4 rates of the `secondary` object")
+    ap.add_argument("--no-signal-check", action="store_true")
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--tile-steps", type=int, default=0)
     ap.add_argument("--meas-per-pass", type=int, default=0)
     ap.add_argument("--gradient-source", type=int, default=0, help="1 = LDS tiles, 2 = scalar loads (0 = default)")
     ap.add_argument("--mesh-traversal", type=int, default=0, help="1 = per lane, 2 = wavefront-cooperative")
     ap.add_argument("--resort-steps", type=int, default=0, help="mesh: steps between walker re-sorts (0 auto, <0 never)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     import torch
 
-    from disimpy_amd import _lib, sharding, simulations
+    from disimpy_amd import _lib, sharding
 
     if _lib.device_count() <= 0:
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
@@ -268,43 +455,19 @@ def main():
     n_dev = max(1, _lib.device_count())
     device = (local_rank if args.backend == "nccl" else local_rank % n_dev) if world > 1 else 0
 
-    default_walkers = {"c1": 1000, "c2": 1_000_000, "c3": 1_000_000, "c4": 1_000_000, "c5": 1_000_000, "c5b": 1_000_000}
-    n_local = args.walkers or default_walkers[args.workload]
-    n_total = n_local * world
-    w = make_workload(args.workload, n_local, args.measurements)
-    sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
+    n_total = args.walkers or DEFAULT_TOTAL_WALKERS[args.workload]
+    t_wl = time.perf_counter()
+    w = make_workload(args.workload, n_total, args.measurements)
+    t_wl = time.perf_counter() - t_wl
+    sub, gradient = w["substrate"], w["gradient"]
     M, T = gradient.shape[0], gradient.shape[1]
-    step_l = float(np.sqrt(6 * w["D"] * dt))
     a, b = sharding.shard_range(n_total, rank, world)
-    assert b - a == n_local
+    n_local = b - a
 
-    # ---- untimed set-up: everything resident in HBM ------------------------------
-    t_setup = time.perf_counter()
-    np.random.seed(123)
-    positions, frames = simulations._initial_positions(n_total, sub, 123, True, device)
-    sim = _lib.Sim(n_local, gradient, dt, step_l, device=device, first_walker=a)
-    sim.set_tuning(args.block_size, args.tile_steps, args.meas_per_pass, args.resort_steps, args.gradient_source,
-                   args.mesh_traversal)
-    t_rng = time.perf_counter()
-    sim.rng_init_device(123)
-    t_rng = time.perf_counter() - t_rng
-    if positions is not None:
-        sim.set_positions(np.ascontiguousarray(positions[a:b], dtype=np.float64))
-    if sub.type == "mesh":
-        sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices,
-                     sub.triangle_indices)
-    t_setup = time.perf_counter() - t_setup
-
-    kernel_ms = []
-    launches = []
-
-    def one_step():
-        simulations._run_range(sim, sub, frames, 1000, 1e-13, 0, T)
-        ms, nl = sim.last_run_ms()
-        kernel_ms.append(ms)
-        launches.append(nl)
-        c, s, nexc = sim.signal()
-        return sharding.reduce_signal(c, s, nexc, dist, device)
+    sim, positions, setup = setup_sim(args, w, n_total, a, b, device)
+    setup["workload_and_mesh_index_host"] = t_wl
+    setup["total"] = sum(setup.values())
+    frames = w["frames"]
 
     def fence():
         if dist is not None:
@@ -312,88 +475,91 @@ def main():
         torch.cuda.synchronize()
 
     first_pass = None
-    for _ in range(args.warmup):
-        r_ = one_step()
-        if first_pass is None:
-            first_pass = r_
-    kernel_ms.clear()
-    launches.clear()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sig = one_step()
-        if first_pass is None:
-            first_pass = sig
-    fence()
-    elapsed = time.perf_counter() - t0
+    if args.warmup:
+        _, _, _, _, first_pass = run_steps(sim, sub, frames, T, args.warmup, dist, device, fence, M)
+    elapsed, walk_ms, run_ms, launches, sig = run_steps(sim, sub, frames, T, args.steps, dist, device, fence, M)
+    if first_pass is None:
+        first_pass = sig
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    spin_steps = float(n_total) * T * args.steps
-    value = spin_steps / elapsed
-    # roofline of the dominant kernel (walk_kernel): algorithmic bytes per launch / launch duration
-    n_launch = max(1, launches[-1])
+    value = float(n_total) * T * args.steps / elapsed
+    # ---- roofline of the dominant kernel (rank 0's shard; every shard runs the same kernel) ----------
+    n_launch = max(1, launches[-1]) if launches else 1
+    walk_ms_step = float(np.mean(walk_ms)) if walk_ms else float("nan")
+    avg_launch_ms = walk_ms_step / n_launch
+    wave_steps_per_s = -(-n_local // 64) * T / (walk_ms_step * 1e-3)
     meas_per_launch = min(M, 32 if not args.meas_per_pass else args.meas_per_pass)
-    # a launch covers all walkers, meas_per_launch measurements and T * passes / n_launch time steps
-    # (mesh runs are cut into one launch per re-sort interval; M > 32 needs several passes)
-    mb_pow2 = 1 << max(0, (meas_per_launch - 1).bit_length())
     passes = -(-M // meas_per_launch)
     steps_per_launch = T * passes / n_launch
-    bytes_per_launch = (80.0 + 16.0 * meas_per_launch) * n_local * steps_per_launch
-    avg_launch_ms = float(np.mean(kernel_ms)) / n_launch
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    traffic = None
-    valu = None  # the bound that actually holds (rocprofv3 SQ counters of the same workload, profiles/)
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            if n_local == default_walkers[args.workload] and not args.meas_per_pass:
-                prof = json.load(open(tfile)).get(args.workload, {})
-                traffic = prof.get("bytes_per_launch")
-                valu = prof.get("valu")
-        except Exception:
-            traffic = None
-
+    alg_bytes_per_launch = (80.0 + 16.0 * meas_per_launch) * n_local * steps_per_launch
+    alg_gbs = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    prof = profile_entry(args.workload) or {}
+    valu_ws = prof.get("valu_per_wave_step")
+    traffic = prof.get("hbm_bytes_per_walker_launch")  # measured HBM bytes per walker and launch (state in + out + misses)
+    traffic = traffic * n_local if traffic else None
+    achieved = valu_ws * wave_steps_per_s if valu_ws else None
+    roofline = {
+        "bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instr/s",
+        "frac": (achieved / VALU_PEAK) if achieved else None,
+        "formula": "VALU wave-instructions per wavefront-step (rocprofv3 SQ_INSTS_VALU / wavefront-steps, "
+                   "profiles/) x wavefront-steps/s (HIP events around the walk kernel in this run) / "
+                   "(1024 SIMDs x 2.4e9 Hz / 4 cycles per wave64 instruction)",
+        "kernel": kernel_name(sub, M, args), "valu_per_wave_step": valu_ws, "salu_per_wave_step": prof.get("salu_per_wave_step"),
+        "valu_busy_measured": prof.get("valu_busy"), "counters_source": prof.get("source"),
+        "wave_steps_per_s": wave_steps_per_s, "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
+        "traffic": traffic,
+        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per walker x "
+                        "this shard's walkers; profiles/)",
+        "hbm": {"achieved": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
+        "algorithmic_hbm": {
+            "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+            "bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch, "bytes_per_launch": alg_bytes_per_launch,
+            "caveat": "SURVEY 8d bytes of the reference's step-synchronous formulation; the time-fused kernel keeps "
+                      "walker state in registers and does not move them, so this is not a utilisation (may exceed 1)"},
+        "note": "register-resident fused kernel: bound by vector-ALU issue and dependent index look-ups, not by "
+                "HBM.  Deviations from the north star's sketch, measured and kept: the mesh kernel reads triangle "
+                "records through L1/L2 (7 MB index, Morton-sorted walkers) instead of staging lists in LDS, and "
+                "with M <= 2 it reads the gradient samples from global memory (32 B per step out of L1) instead "
+                "of an LDS tile; LDS holds the log/cos tables, the subvoxel boundaries and the wave work queues.",
+    }
     out = {
         "metric": "spin-steps/sec", "value": value, "unit": "spin-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": w["label"], "walkers_per_gpu": n_local, "time_steps": T, "measurements": M,
-            "substrate": sub.type, "seed": 123, "sharding": "walker ranges, 1 RCCL all-reduce of 2M+1 f64 per step",
+            "workload": w["label"], "total_walkers": n_total, "walkers_per_gpu": n_local, "time_steps": T,
+            "measurements": M, "substrate": sub.type, "triangles": int(len(sub.faces)) if sub.type == "mesh" else 0,
+            "seed": 123, "sharding": "balanced walker ranges, 1 all-reduce of 2M+1 f64 per step (%s)" % args.backend,
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 "
-            "FETCH_SIZE x2 + WRITE_SIZE, separate passes, calibrated: profiles/hbm_traffic.json)",
-            "traffic_GBps": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "kernel": ("walk_kernel<%s,%d>" % (sub.type, mb_pow2) if sub.type != "mesh" or args.mesh_traversal == 1
-                       else "walk_kernel_coop4<%d>" % mb_pow2 if mb_pow2 <= 2
-                       else "walk_kernel_coop4_traj + phase_from_traj_kernel<%d>" % mb_pow2),
-            "algorithmic_bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch,
-            "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms, "valu": valu,
-            "note": "time-fused kernel: walker state stays in registers, so real HBM traffic (traffic) is far "
-                    "below the algorithmic bytes of the reference's step-synchronous formulation; the kernel "
-                    "is fp64-VALU bound",
-        },
-        "kernel_spin_steps_per_s": n_local * T / (float(np.mean(kernel_ms)) * 1e-3),
-        "setup_s": {"total": t_setup, "rng_init_device": t_rng},
-        # first pass over the waveform starts from the initial state: C2 expects exp(-bD) = exp(-2) = 0.1353
+        "roofline": roofline,
+        "walk_kernel_spin_steps_per_s": n_local * T / (walk_ms_step * 1e-3),
+        "run_spin_steps_per_s": n_local * T / (float(np.mean(run_ms)) * 1e-3) if run_ms else None,
+        "setup_s": setup,
+        # first pass over the waveform starts from the initial state: free diffusion expects exp(-bD)
         "signal_check": {"first_pass_mean_S_over_N": float(np.mean(first_pass[0]) / n_total),
                          "last_pass_mean_S_over_N": float(np.mean(sig[0]) / n_total)},
     }  # fmt: skip
+    if sim is not None:
+        sim.close()
+    if rank == 0 and positions is None:
+        positions = np.zeros((1, 3))
+    if rank == 0 and not args.no_signal_check:
+        out["signal_rel_err"] = signal_rel_err(w, positions, device)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(w)
-    sim.close()
+        out["cpu_baseline"] = cpu_baseline(w, positions)
+    if rank == 0 and not args.no_secondary and world == 1:
+        out["secondary"] = secondary_rates(args, device)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

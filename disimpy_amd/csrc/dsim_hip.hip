@@ -228,6 +228,11 @@ struct dsim_sim {
   DevMesh mesh;
   double last_ms = 0;
   int last_launches = 0;
+  /* events around every launch of the walk kernel itself (the run also contains sort / gather /
+   * phase kernels): bench.py's roofline is computed from these */
+  std::vector<hipEvent_t> walk_ev;
+  int walk_ev_used = 0;
+  double last_walk_ms = 0;
   int block_size = 256, tile_steps = 0, meas_per_pass = 0;
   int resort_steps = 0; /* mesh: 0 = automatic, < 0 = never re-sort the walkers */
   int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
@@ -297,6 +302,7 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->iota) (void)hipFree(h->iota);
   if (h->sort_tmp) (void)hipFree(h->sort_tmp);
   free_mesh(h->mesh);
+  for (hipEvent_t e : h->walk_ev) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -906,6 +912,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   HIP_TRY(hipSetDevice(h->device));
   h->last_ms = 0;
   h->last_launches = 0;
+  h->last_walk_ms = 0;
+  h->walk_ev_used = 0;
   if (t_begin == t_end) return DSIM_OK;
   const int mb_all = pick_mb(h->M, h->meas_per_pass);
   const int passes_all = (h->M + mb_all - 1) / mb_all;
@@ -924,6 +932,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
    * recording variant) */
   const int mb = split_phase ? 1 : (record_extra ? 32 : mb_all);
   const int passes = record ? 1 : passes_all;
+  /* measurements the walk kernel itself accumulates in a recording run: none when the phases come
+   * from the recorded positions, otherwise the first min(32, M) whatever meas_per_pass says (the
+   * 32-accumulator kernel is the only one with a recording variant) */
+  const int walk_meas = split_phase ? 0 : (record_extra ? std::min(32, h->M) : 0);
   p.n = h->n;
   p.g4 = h->g4;
   p.M = h->M;
@@ -1002,6 +1014,9 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   }
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   bool permuted = false;
+  /* the time loop; any failure inside leaves through `return`, and the walker order is put back
+   * below before the error is reported (getters must never see Morton order) */
+  auto time_loop = [&]() -> int {
   for (int ca = t_begin; ca < t_end;) {
     const int cb = resort > 0 ? std::min(t_end, ca + resort) : t_end;
     if (resort > 0) {
@@ -1032,6 +1047,14 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       p.mc = split_phase ? 0 : std::min(mb, h->M - p.m0);
       p.write_state = pass == passes - 1;
       hipError_t e;
+      if (h->walk_ev_used + 2 > (int)h->walk_ev.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreate(&a));
+        h->walk_ev.push_back(a);
+        HIP_TRY(hipEventCreate(&b));
+        h->walk_ev.push_back(b);
+      }
+      HIP_TRY(hipEventRecord(h->walk_ev[h->walk_ev_used], h->stream));
       switch (geom) {
         case GEOM_FREE: e = launch_mb<GEOM_FREE>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
         case GEOM_SPHERE: e = launch_mb<GEOM_SPHERE>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
@@ -1040,6 +1063,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
         default: e = launch_mb<GEOM_MESH>(mb, p, grid, block, lds, h->stream, h->grad_src, coop); break;
       }
       if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+      HIP_TRY(hipEventRecord(h->walk_ev[h->walk_ev_used + 1], h->stream));
+      h->walk_ev_used += 2;
       h->last_launches++;
     }
     h->cur = dst;
@@ -1047,8 +1072,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       const int tile_p = std::max(1, 16384 / (mb_all * 32));
       const size_t lds_p = (size_t)tile_p * mb_all * 4 * sizeof(double);
       const int grid_p = grid_for(h->n, 256);
-      for (int pass = split_phase ? 0 : 1; pass < passes_all; pass++) {
-        const int m0 = pass * mb_all, mc = std::min(mb_all, h->M - m0);
+      for (int m0 = walk_meas; m0 < h->M; m0 += mb_all) {
+        const int mc = std::min(mb_all, h->M - m0);
 #define DSIM_PHASE_LAUNCH(MBV)                                                                                             \
   phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(h->traj, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \
                                                                  p.gdt, h->phase)
@@ -1068,10 +1093,20 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
    }
     ca = cb;
   }
+  return DSIM_OK;
+  };
+  const int loop_rc = time_loop();
   if (permuted) {
+    const std::string keep = g_err;
     int rc = restore_walker_order(h);
+    if (loop_rc) {
+      (void)hipStreamSynchronize(h->stream);
+      g_err = keep;
+      return loop_rc;
+    }
     if (rc) return rc;
   }
+  if (loop_rc) return loop_rc;
   if (h->recording) {
     h->rec_t0 = t_begin;
     h->rec_t1 = t_end;
@@ -1081,6 +1116,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
+  for (int i = 0; i + 1 < h->walk_ev_used; i += 2) {
+    float w = 0;
+    HIP_TRY(hipEventElapsedTime(&w, h->walk_ev[i], h->walk_ev[i + 1]));
+    h->last_walk_ms += w;
+  }
   return DSIM_OK;
 }
 
@@ -1142,6 +1182,13 @@ extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) 
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_ms;
   if (n_launches) *n_launches = h->last_launches;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (ms) *ms = h->last_walk_ms;
+  if (n_launches) *n_launches = h->walk_ev_used / 2;
   return DSIM_OK;
 }
 

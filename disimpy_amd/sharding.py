@@ -1,8 +1,9 @@
 """Walker sharding across the GPUs of one node (one process per GPU).
 
 Walkers are independent; the only cross-walker operation of the path is the
-final signal sum.  GPU g of G owns the contiguous global walker range
-[g*ceil(N/G), min(N, (g+1)*ceil(N/G))); walker i ALWAYS uses RNG state i and
+final signal sum.  GPU g of G owns a contiguous global walker range of
+floor(N/G) or floor(N/G)+1 walkers (balanced split; a rank whose range is empty
+skips the GPU work and contributes zeros); walker i ALWAYS uses RNG state i and
 initial position i, so results do not depend on G except for floating-point
 summation order.  The single collective is one all-reduce (sum, float64,
 2*M + 1 values: sum cos, sum sin, exceeded-walker count) over
@@ -21,9 +22,9 @@ def shard_range(n_walkers, rank, world_size):
     """[a, b) of global walker indices owned by ``rank``."""
     if world_size < 1 or not (0 <= rank < world_size):
         raise ValueError("bad rank/world_size")
-    per = -(-n_walkers // world_size)
-    a = min(n_walkers, rank * per)
-    return a, min(n_walkers, a + per)
+    base, extra = divmod(n_walkers, world_size)  # the first `extra` ranks own one walker more
+    a = rank * base + min(rank, extra)
+    return a, a + base + (1 if rank < extra else 0)
 
 
 def reduce_signal(cos_sum, sin_sum, n_exceeded, dist=None, device=None):
@@ -56,6 +57,10 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
     simulations._validate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, 128, max_iter)
     np.random.seed(seed)
     a, b = shard_range(n_walkers, rank, world)
+    if b == a:  # more ranks than walkers: nothing to simulate here, but the collective still needs this rank
+        M = gradient.shape[0]
+        c, s, nexc = reduce_signal(np.zeros(M), np.zeros(M), 0, dist, device)
+        return c
     res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, max_iter, epsilon,
                                 device=device or 0, walker_range=(a, b))
     c, s, nexc = reduce_signal(res["cos"], res["sin"], res["n_exceeded"], dist, device)

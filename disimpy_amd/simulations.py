@@ -43,8 +43,12 @@ def _rejection_sample(rng, n, dim, scale, inside):
 
 def _host_rng(seed):
     """The reference seeds numba's CPU Mersenne Twister with ``np.random.seed(seed)``
-    inside a jitted function (disimpy/simulations.py:346-350); numba documents
-    it as the same MT19937 + 53-bit doubles as NumPy's legacy ``RandomState``."""
+    inside a jitted function (disimpy/simulations.py:346-350) and draws with
+    ``np.random.random(k)``.  Read from numba's source (tests/test_r16_numba_mt19937.py
+    restates it line by line): the seed goes through MT19937 ``init_genrand``
+    (numba/_random.c:58-71 via numba/cpython/randomimpl.py:207-219) and a double is
+    ``(a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53`` (randomimpl.py:133-146) - the same
+    stream as NumPy's legacy ``RandomState(seed).random_sample``."""
     return np.random.RandomState(seed)
 
 
@@ -183,37 +187,51 @@ def _validate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         raise ValueError("Incorrect value (%s) for max_iter" % max_iter)
 
 
-def _initial_positions(n_walkers, substrate, seed, quiet, device):
-    """Initial positions of ALL walkers (global index order) and the per-substrate
-    launch closure.  Returns (positions or None for zeros, run(sim, t0, t1))."""
+def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=None):
+    """Initial positions of the walkers [a, b) = ``walker_range`` (default: all) and the
+    substrate's rotation frames.  Returns (positions (b - a, 3) or None for zeros, frames).
+
+    Walker i always starts at row i of the reference's (n_walkers, 3) array, whatever the
+    range.  What a shard has to compute for that:
+
+    * analytic substrates (host rejection streams, disimpy/simulations.py:353-418): the
+      stream is sequential and acceptance is data dependent, so the first b points are
+      drawn (a few tens of ns each) and rows [a, b) kept - nothing beyond b is generated;
+    * mesh, ``init_pos="uniform"`` (:1347): the first 3 b draws of the global NumPy stream;
+    * mesh, ``init_pos="intra"/"extra"`` (:505-579): every launch of the reference's fill
+      kernel appends its accepted points in thread order, so row i depends on the outcome
+      of all earlier threads and launches; each rank runs the whole device fill (4 to 30 s)
+      on its own GPU - in parallel, so the wall time equals the single-GPU case - and keeps
+      its rows."""
+    a, b = (0, n_walkers) if walker_range is None else walker_range
     kind = substrate.type
     if kind == "free":
         return None, None
     if kind == "cylinder":
         R = utils.vec2vec_rotmat(substrate.orientation, np.array([1.0, 0, 0]))
         R_inv = np.linalg.inv(R)
-        pos = _initial_positions_cylinder(n_walkers, substrate.radius, R_inv, _host_rng(seed))
-        return pos, (R, R_inv)
+        pos = _initial_positions_cylinder(b, substrate.radius, R_inv, _host_rng(seed))
+        return pos[a:b], (R, R_inv)
     if kind == "sphere":
-        return _fill_sphere(n_walkers, substrate.radius, _host_rng(seed)), None
+        return _fill_sphere(b, substrate.radius, _host_rng(seed))[a:b], None
     if kind == "ellipsoid":
         R_inv = substrate.R
         R = np.linalg.inv(R_inv)
-        pos = _initial_positions_ellipsoid(n_walkers, substrate.semiaxes, R_inv, _host_rng(seed))
-        return pos, (R, R_inv)
+        pos = _initial_positions_ellipsoid(b, substrate.semiaxes, R_inv, _host_rng(seed))
+        return pos[a:b], (R, R_inv)
     if kind == "mesh":
         if isinstance(substrate.init_pos, np.ndarray):
             if n_walkers != substrate.init_pos.shape[0]:
                 raise ValueError("n_walkers must be equal to the number of initial positions")
-            return substrate.init_pos, None
+            return substrate.init_pos[a:b], None
         if not quiet:
             print("Calculating initial positions")
         if substrate.init_pos == "uniform":
-            pos = np.random.random((n_walkers, 3)) * substrate.voxel_size
+            pos = (np.random.random((b, 3)) * substrate.voxel_size)[a:b]
         elif substrate.init_pos == "intra":
-            pos = _fill_mesh(n_walkers, substrate, True, seed, device=device)
+            pos = _fill_mesh(n_walkers, substrate, True, seed, device=device)[a:b]
         else:
-            pos = _fill_mesh(n_walkers, substrate, False, seed, device=device)
+            pos = _fill_mesh(n_walkers, substrate, False, seed, device=device)[a:b]
         if not quiet:
             print("Finished calculating initial positions")
         return pos, None
@@ -250,16 +268,16 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         print("Number of steps = %s" % n_t)
         print("Step length = %s m" % step_l)
         print("Step duration = %s s" % dt)
-    positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device)
+    positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b))
     with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a) as sim:
         sim.rng_init_device(seed)
         if positions is not None:
-            sim.set_positions(np.ascontiguousarray(positions[a:b], dtype=np.float64))
+            sim.set_positions(np.ascontiguousarray(positions, dtype=np.float64))
         if substrate.type == "mesh":
             sim.set_mesh(substrate.vertices, substrate.faces, substrate.xs, substrate.ys, substrate.zs,
                          substrate.n_sv, substrate.subvoxel_indices, substrate.triangle_indices)
         if traj:
-            _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions[a:b]))
+            _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions))
         if traj:
             # the trajectories file needs the positions after every step: the device records them
             # and hands them over once per range of steps (<= 64 MB) instead of once per step
@@ -269,6 +287,11 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             chunk = n_t
         else:
             chunk = max(1, int(math.ceil(n_t / 100)))  # progress is reported at range boundaries
+            if substrate.type == "mesh":
+                # every run_mesh call re-sorts the walkers by position and restores their order at
+                # the end (about 20 time steps' worth of work): never cut a mesh run finer than the
+                # library's own re-sort interval
+                chunk = max(chunk, 1024)
         ms_total = 0.0
         for t0 in range(0, n_t, chunk):
             t1 = min(n_t, t0 + chunk)

@@ -145,6 +145,12 @@ int dsim_interval_sv_overlap(const double *xs, int64_t n_xs, double x1, double x
  * kernel launches it made, and the name of the kernel. */
 int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
 
+/* The same call's time inside the walk kernel alone (HIP events recorded on the library's
+ * stream immediately before and after every launch of walk_kernel*, summed), and the number of
+ * those launches: the run also contains the re-sort, gather and phase kernels.  bench.py's
+ * roofline of the dominant kernel is computed from this figure. */
+int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches);
+
 /* Trajectories (replaces the reference's per-step `positions.copy_to_host()` + file append of
  * simulations.py:1043-1048, :1211-1213 by one transfer per range of steps).
  * dsim_set_recording(h, 1): every following dsim_run_* call keeps the position of every walker

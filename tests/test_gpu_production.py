@@ -1,0 +1,181 @@
+"""GPU parity at production shape (run with ``-m gpu``): the combinations the headline bench
+actually exercises - the neuron with automatic Morton re-sorting over several re-sort intervals
+and launches of the 4-waves/SIMD cooperative kernel, the packed-cylinder mesh of BASELINE config
+C4, and the 50 000-triangle refinement (C5b) - each bit-identical, walker by walker, to the
+exact CPU oracle (OpenMP over walkers; reference: disimpy/simulations.py:878-1013).
+"""
+import os
+import sys
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from conftest import ROOT, golden
+from oracle.oracle import FREE, MESH, SPHERE
+from test_gpu_parity import D, _assert_identical, _gpu_run, _mesh_arrays, _random_gradient
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+THREADS = os.cpu_count() or 1
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from disimpy_amd import _lib
+
+    assert _lib.device_count() > 0, "these tests need an AMD GPU"
+    return _lib
+
+
+def _oracle_mesh(o, ma, n, g, dt, step_l, pos0, seed, perm_prob=0.0, want_traj=False):
+    st = o.rng_states(n, seed)
+    pos = np.array(pos0, dtype=np.float64, order="C")
+    geom = o.geom(MESH, mesh=ma, max_iter=1000, epsilon=1e-13, perm_prob=perm_prob)
+    ph, exc, traj = o.run(geom, g, dt, step_l, pos, st, n_threads=THREADS, want_traj=want_traj)
+    c, s = o.signal(ph, exc)
+    return dict(pos=pos, phases=ph, exc=exc.astype(bool), states=np.stack([st["s0"], st["s1"]], axis=1), cos=c, sin=s,
+                traj=traj)
+
+
+def test_neuron_production_shape_resorted_launches(lib, oracle_exact):
+    """Neuron (29 688 triangles, 50^3 index, walkers inside), the C5 step length, 8192 walkers x
+    2200 steps: automatic re-sort interval (1024 steps => 3 sorts, 3 launches of
+    walk_kernel_coop4, XCD-aware group mapping, walkers advancing at their own pace)."""
+    from disimpy_amd import simulations, substrates
+
+    m = golden("neuron_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), True, init_pos="intra", quiet=True)
+    n, T, dt = 8192, 2200, 7e-6
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(1, T)
+    pos0 = simulations._fill_mesh(n, sub, True, 123)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    with lib.Sim(n, g, dt, step_l) as sim:  # default tuning: what bench.py runs
+        sim.rng_init_device(123)
+        sim.set_positions(pos0)
+        sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+        sim.run_mesh(1000, 1e-13, 0.0, 0, T)
+        assert sim.last_run_ms()[1] >= 3 and sim.last_walk_ms()[1] >= 3  # >= 2 re-sort intervals, >= 2 launches
+        c, s, _ = sim.signal()
+        gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
+    _assert_identical(gpu, ref)
+    assert (gpu["pos"].max(axis=0) < sub.voxel_size).all() and (gpu["pos"].min(axis=0) > 0).all()
+    del kw
+
+
+def test_c4_packed_cylinders_bit_identical(lib, oracle_exact):
+    """BASELINE config C4 (bench.packed_cylinders: 4096 triangles, periodic, uniform positions,
+    50^3 index), 4096 walkers x 500 steps of the C4 waveform's step length, re-sorted every 128 steps."""
+    from disimpy_amd import substrates
+
+    v, f = bench.packed_cylinders()
+    sub = substrates.mesh(v, f, True, init_pos="uniform", quiet=True)
+    n, T, dt = 4096, 500, 7e-6
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(2, T)
+    pos0 = np.random.RandomState(123).random_sample((n, 3)) * sub.voxel_size
+    ma = _mesh_arrays(sub)
+    ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    for tuning in (None, dict(resort_steps=128)):
+        gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma, tuning=tuning)
+        _assert_identical(gpu, ref)
+    # walkers that start inside a cylinder (r = 1 um around the lattice points) stay inside
+    def inside(p):
+        q = np.mod(p[:, :2], 2.5e-6) - 1.25e-6
+        return np.linalg.norm(q, axis=1) < 1e-6 * np.cos(np.pi / 32)  # inscribed circle of the 32-gon
+    was_in = inside(pos0)
+    q = np.mod(gpu["pos"][:, :2], 2.5e-6) - 1.25e-6
+    assert (np.linalg.norm(q[was_in], axis=1) < 1e-6).all()
+
+
+def test_c5b_refined_neuron_bit_identical(lib, oracle_exact):
+    """The 50 000-triangle refinement of the neuron that bench.py runs by default (C5b), small size."""
+    from disimpy_amd import simulations, substrates
+
+    m = golden("neuron_mesh.npz")
+    v, f = bench.split_longest_edges(m["vertices"], m["faces"], 50000)
+    assert len(f) == 50000
+    sub = substrates.mesh(v, f, True, init_pos="intra", quiet=True)
+    n, T, dt = 4096, 600, 7e-6
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(1, T)
+    pos0 = simulations._fill_mesh(n, sub, True, 123)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma, tuning=dict(resort_steps=256))
+    _assert_identical(gpu, ref)
+
+
+@pytest.mark.parametrize("meas_per_pass", [1, 8])
+@pytest.mark.parametrize("M", [3, 20, 40])
+def test_recording_with_forced_measurements_per_pass(lib, oracle_exact, M, meas_per_pass):
+    """Recording + a forced meas_per_pass < 32: the recording walk kernel carries min(32, M)
+    measurements itself, the follow-up passes must start after them (round-1 advisor finding:
+    measurements 8..19 were accumulated twice)."""
+    n, T, dt = 1200, 40, 1e-4
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(M, T)
+    st = oracle_exact.rng_states(n, 42)
+    pos = np.zeros((n, 3))
+    ph, exc, traj = oracle_exact.run(oracle_exact.geom(FREE), g, dt, step_l, pos, st, want_traj=True)
+    with lib.Sim(n, g, dt, step_l) as sim:
+        sim.set_tuning(meas_per_pass=meas_per_pass)
+        sim.rng_init_device(42)
+        sim.set_recording(True)
+        sim.run_free(0, T)
+        rec = sim.recorded(0, T)
+        got = sim.phases()
+        npt.assert_array_equal(sim.positions(), pos)
+    npt.assert_array_equal(got, ph)
+    npt.assert_array_equal(rec, traj)
+
+
+@pytest.mark.parametrize("kind", ["free", "sphere", "mesh"])
+def test_recorded_trajectories_equal_the_oracles(lib, oracle_exact, kind):
+    """dsim_set_recording / dsim_get_recorded against the ORACLE's per-step positions (want_traj:
+    what the reference writes to its trajectories file, simulations.py:1043-1048, :1211-1213)."""
+    from disimpy_amd import substrates
+
+    n, T, dt = 5000, 30, 5e-4
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(2, T)
+    st = oracle_exact.rng_states(n, 77)
+    if kind == "free":
+        pos0 = np.zeros((n, 3))
+        geom = oracle_exact.geom(FREE)
+    elif kind == "sphere":
+        pos0 = (np.random.RandomState(4).random_sample((n, 3)) - 0.5) * 2e-6
+        geom = oracle_exact.geom(SPHERE, radius=2e-6, max_iter=1000, epsilon=1e-13)
+    else:
+        m = golden("cylinder_mesh_closed.npz")
+        sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.array([1e-6, 1e-6, 0.0]), n_sv=np.array([6, 6, 12]),
+                              quiet=True)
+        pos0 = np.random.RandomState(4).random_sample((n, 3)) * sub.voxel_size
+        geom = oracle_exact.geom(MESH, mesh=_mesh_arrays(sub), max_iter=1000, epsilon=1e-13)
+    pos = pos0.copy()
+    ph, exc, traj = oracle_exact.run(geom, g, dt, step_l, pos, st, want_traj=True, n_threads=THREADS)
+    with lib.Sim(n, g, dt, step_l) as sim:
+        sim.rng_init_device(77)
+        sim.set_positions(pos0)
+        if kind == "mesh":
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+        sim.set_recording(True)
+        rec = []
+        for t0, t1 in ((0, 17), (17, T)):
+            if kind == "free":
+                sim.run_free(t0, t1)
+            elif kind == "sphere":
+                sim.run_sphere(2e-6, 1000, 1e-13, t0, t1)
+            else:
+                sim.run_mesh(1000, 1e-13, 0.0, t0, t1)
+            rec.append(sim.recorded(t0, t1))
+        got_ph = sim.phases()
+    npt.assert_array_equal(np.concatenate(rec), traj)
+    npt.assert_array_equal(got_ph, ph)
