@@ -19,6 +19,7 @@ SYMBOLS = (
     "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
+    "dsim_write_traj", "dsim_write_traj_line",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -77,6 +78,8 @@ def load():
     lib.dsim_set_tuning.argtypes = [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.dsim_set_recording.argtypes = [_h, C.c_int32]
     lib.dsim_get_recorded.argtypes = [_h, C.c_int32, C.c_int32, _f64p]
+    lib.dsim_write_traj.argtypes = [_h, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.dsim_write_traj_line.argtypes = [C.c_char_p, _f64p, C.c_int64, C.c_int32]
     _lib = lib
     return lib
 
@@ -235,6 +238,10 @@ class Sim:
         check(self._lib.dsim_get_recorded(self._h, t0, t1, p_f64(out)))
         return np.ascontiguousarray(out.transpose(0, 2, 1))
 
+    def write_traj(self, path, t0, t1, append=True):
+        """Lines of steps t0 .. t1-1 of the last recorded run_* call -> the trajectories file."""
+        check(self._lib.dsim_write_traj(self._h, os.fsencode(path), t0, t1, 1 if append else 0))
+
     def last_run_ms(self):
         ms, nl = C.c_double(0), C.c_int32(0)
         check(self._lib.dsim_last_run_ms(self._h, C.byref(ms), C.byref(nl)))
@@ -272,6 +279,13 @@ class Sim:
         out = np.zeros((self.n, 2), dtype=np.uint64)
         check(self._lib.dsim_get_rng_states(self._h, p_u64(out)))
         return out
+
+
+def write_traj_line(path, positions, append=False):
+    """One line of the trajectories file from a host array (n, 3): ``str(v) + " "`` per value."""
+    pos = _c(positions, np.float64)
+    assert pos.ndim == 2 and pos.shape[1] == 3
+    check(load().dsim_write_traj_line(os.fsencode(path), p_f64(pos), len(pos), 1 if append else 0))
 
 
 def fill_mesh(n_points, intra, seed, vertices, faces, voxel_size, xs, ys, zs, n_sv, subvoxel_indices,

@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsim.h"
@@ -242,6 +244,12 @@ struct dsim_sim {
   double *phase_alt = nullptr;
   double *traj = nullptr; /* [steps][3][n] positions of the last launch (mesh with M > 2: phases from positions) */
   int traj_steps = 0;
+  /* hand-over of recorded positions: a copy stream of its own and two pinned staging buffers, so that the
+   * D2H transfer of one block of steps overlaps the host's work (copy-out / text formatting) on the previous one */
+  hipStream_t copy_stream = nullptr;
+  void *pin[2] = {nullptr, nullptr};
+  size_t pin_bytes = 0;
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool recording = false;        /* dsim_set_recording: keep the positions of every step of a run */
   int rec_t0 = 0, rec_t1 = 0;    /* time range held in traj after a recorded run */
   uint8_t *exc_alt = nullptr;
@@ -303,6 +311,11 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->sort_tmp) (void)hipFree(h->sort_tmp);
   free_mesh(h->mesh);
   for (hipEvent_t e : h->walk_ev) (void)hipEventDestroy(e);
+  for (int b = 0; b < 2; b++) {
+    if (h->pin[b]) (void)hipHostFree(h->pin[b]);
+    if (h->pin_ev[b]) (void)hipEventDestroy(h->pin_ev[b]);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1165,17 +1178,210 @@ extern "C" int dsim_set_recording(dsim_handle h, int32_t enable) {
   return DSIM_OK;
 }
 
+/* ---- recorded positions -> host, double buffered ------------------------------------------------
+ * Steps [t_begin, t_end) of the last recorded run are handed to `sink` block by block.  Blocks go
+ * through two pinned staging buffers on a dedicated copy stream: while the host consumes block k
+ * (copies it out, or formats it as text), the DMA engine is already filling the other buffer with
+ * block k+1.  sink(first_step, n_steps, data) sees the device layout [step][3][n]. */
+static int fetch_recorded(dsim_sim *h, int32_t t_begin, int32_t t_end, const std::function<int(int, int, const double *)> &sink) {
+  const size_t row = (size_t)3 * h->n * sizeof(double);
+  const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)(t_end - t_begin), ((size_t)32 << 20) / row));
+  const size_t need = (size_t)per * row;
+  if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++)
+    if (!h->pin_ev[b]) HIP_TRY(hipEventCreateWithFlags(&h->pin_ev[b], hipEventDisableTiming));
+  if (h->pin_bytes < need) {
+    for (int b = 0; b < 2; b++) {
+      if (h->pin[b]) (void)hipHostFree(h->pin[b]);
+      h->pin[b] = nullptr;
+    }
+    h->pin_bytes = 0;
+    for (int b = 0; b < 2; b++) HIP_TRY(hipHostMalloc(&h->pin[b], need, hipHostMallocDefault));
+    h->pin_bytes = need;
+  }
+  auto issue = [&](int t0, int b) -> int {
+    const int cnt = std::min(per, t_end - t0);
+    HIP_TRY(hipMemcpyAsync(h->pin[b], h->traj + (size_t)(t0 - h->rec_t0) * 3 * h->n, (size_t)cnt * row, hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(hipEventRecord(h->pin_ev[b], h->copy_stream));
+    return DSIM_OK;
+  };
+  int rc = issue(t_begin, 0);
+  if (rc) return rc;
+  int b = 0;
+  for (int t0 = t_begin; t0 < t_end; t0 += per, b ^= 1) {
+    if (t0 + per < t_end) {
+      rc = issue(t0 + per, b ^ 1); /* the other buffer: its previous block has been consumed already */
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventSynchronize(h->pin_ev[b]));
+    rc = sink(t0, std::min(per, t_end - t0), (const double *)h->pin[b]);
+    if (rc) {
+      (void)hipStreamSynchronize(h->copy_stream);
+      return rc;
+    }
+  }
+  return DSIM_OK;
+}
+
+static int check_recorded_range(dsim_sim *h, const char *who, int32_t t_begin, int32_t t_end) {
+  if (!h->recording || !h->traj) return fail(DSIM_ERR_STATE, "%s: recording is off", who);
+  if (t_begin < h->rec_t0 || t_end > h->rec_t1 || t_begin > t_end)
+    return fail(DSIM_ERR_INVALID, "%s: [%d, %d) outside the recorded range [%d, %d)", who, t_begin, t_end, h->rec_t0, h->rec_t1);
+  return DSIM_OK;
+}
+
 extern "C" int dsim_get_recorded(dsim_handle h, int32_t t_begin, int32_t t_end, double *out) {
   if (!h || !out) return fail(DSIM_ERR_INVALID, "dsim_get_recorded: null argument");
-  if (!h->recording || !h->traj) return fail(DSIM_ERR_STATE, "dsim_get_recorded: recording is off");
-  if (t_begin < h->rec_t0 || t_end > h->rec_t1 || t_begin > t_end)
-    return fail(DSIM_ERR_INVALID, "dsim_get_recorded: [%d, %d) outside the recorded range [%d, %d)", t_begin, t_end, h->rec_t0, h->rec_t1);
+  int rc = check_recorded_range(h, "dsim_get_recorded", t_begin, t_end);
+  if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));
   if (t_begin == t_end) return DSIM_OK;
-  const size_t row = (size_t)3 * h->n * sizeof(double);
-  HIP_TRY(hipMemcpyAsync(out, h->traj + (size_t)(t_begin - h->rec_t0) * 3 * h->n, (size_t)(t_end - t_begin) * row, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  const size_t row_doubles = (size_t)3 * h->n;
+  return fetch_recorded(h, t_begin, t_end, [&](int t0, int cnt, const double *src) {
+    memcpy(out + (size_t)(t0 - t_begin) * row_doubles, src, (size_t)cnt * row_doubles * sizeof(double));
+    return DSIM_OK;
+  });
+}
+
+/* ---- trajectories file (simulations.py:1043-1048) ------------------------------------------------
+ * The reference writes `str(value) + " "` for every coordinate and "\n" per time step.  str() of a
+ * float is the shortest decimal string that round-trips, laid out by CPython's float_repr_style
+ * "short" rules: scientific notation iff the decimal exponent is < -4 or >= 16, at least two exponent
+ * digits, ".0" appended to integral values in fixed notation.  std::to_chars gives the same shortest
+ * digits; the layout is redone here.  Returns the number of characters written (<= 24). */
+static size_t format_py_float(double x, char *out) {
+  if (x != x) {
+    memcpy(out, "nan", 3);
+    return 3;
+  }
+  char *p = out;
+  if (std::signbit(x)) {
+    *p++ = '-';
+    x = -x;
+  }
+  if (x == std::numeric_limits<double>::infinity()) {
+    memcpy(p, "inf", 3);
+    return (size_t)(p + 3 - out);
+  }
+  if (x == 0) {
+    memcpy(p, "0.0", 3);
+    return (size_t)(p + 3 - out);
+  }
+  char tmp[40], digits[24];
+  const auto r = std::to_chars(tmp, tmp + sizeof(tmp), x, std::chars_format::scientific); /* d[.ddd]e[+-]XX, shortest */
+  int nd = 0;
+  const char *q = tmp;
+  digits[nd++] = *q++;
+  if (*q == '.')
+    for (q++; *q != 'e'; q++) digits[nd++] = *q;
+  q++;
+  const bool eneg = *q++ == '-';
+  int e = 0;
+  while (q < r.ptr) e = e * 10 + (*q++ - '0');
+  const int decpt = (eneg ? -e : e) + 1; /* value = 0.d1d2... x 10^decpt */
+  if (decpt <= -4 || decpt > 16) {
+    *p++ = digits[0];
+    if (nd > 1) {
+      *p++ = '.';
+      memcpy(p, digits + 1, (size_t)nd - 1);
+      p += nd - 1;
+    }
+    *p++ = 'e';
+    int ex = decpt - 1;
+    *p++ = ex < 0 ? '-' : '+';
+    if (ex < 0) ex = -ex;
+    if (ex >= 100) {
+      *p++ = (char)('0' + ex / 100);
+      ex %= 100;
+    }
+    *p++ = (char)('0' + ex / 10);
+    *p++ = (char)('0' + ex % 10);
+  } else if (decpt <= 0) {
+    *p++ = '0';
+    *p++ = '.';
+    for (int i = 0; i < -decpt; i++) *p++ = '0';
+    memcpy(p, digits, (size_t)nd);
+    p += nd;
+  } else if (decpt >= nd) {
+    memcpy(p, digits, (size_t)nd);
+    p += nd;
+    for (int i = 0; i < decpt - nd; i++) *p++ = '0';
+    *p++ = '.';
+    *p++ = '0';
+  } else {
+    memcpy(p, digits, (size_t)decpt);
+    p += decpt;
+    *p++ = '.';
+    memcpy(p, digits + decpt, (size_t)(nd - decpt));
+    p += nd - decpt;
+  }
+  return (size_t)(p - out);
+}
+
+/* One line of the file = the n walkers of one time step, "x y z x y z ... \n"; x/y/z point at the
+ * three coordinates of walker 0 and advance by `stride` doubles per walker (1 for the device's
+ * component-major layout, 3 for (n,3) row-major host arrays).  Walker ranges are formatted by a few
+ * host threads into private buffers and written in order. */
+static int write_traj_lines(FILE *f, int64_t n, int n_lines, const double *base, size_t line_stride, const double *x_off,
+                            const double *y_off, const double *z_off, size_t stride) {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw, 32u), n / 2048));
+  std::vector<std::vector<char>> bufs((size_t)n_thr);
+  for (int line = 0; line < n_lines; line++) {
+    const double *px = x_off + (size_t)line * line_stride, *py = y_off + (size_t)line * line_stride, *pz = z_off + (size_t)line * line_stride;
+    auto work = [&](int k) {
+      const int64_t a = n * k / n_thr, b = n * (k + 1) / n_thr;
+      std::vector<char> &buf = bufs[(size_t)k];
+      buf.resize((size_t)(b - a) * 3 * 25 + 2);
+      char *p = buf.data();
+      for (int64_t i = a; i < b; i++) {
+        p += format_py_float(px[(size_t)i * stride], p);
+        *p++ = ' ';
+        p += format_py_float(py[(size_t)i * stride], p);
+        *p++ = ' ';
+        p += format_py_float(pz[(size_t)i * stride], p);
+        *p++ = ' ';
+      }
+      if (k == n_thr - 1) *p++ = '\n';
+      buf.resize((size_t)(p - buf.data()));
+    };
+    if (n_thr == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int k = 0; k < n_thr; k++) th.emplace_back(work, k);
+      for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < n_thr; k++)
+      if (fwrite(bufs[(size_t)k].data(), 1, bufs[(size_t)k].size(), f) != bufs[(size_t)k].size()) return fail(DSIM_ERR_STATE, "trajectories file: write failed");
+  }
+  (void)base;
   return DSIM_OK;
+}
+
+extern "C" int dsim_write_traj_line(const char *path, const double *positions_aos, int64_t n_walkers, int32_t append) {
+  if (!path || !positions_aos || n_walkers <= 0) return fail(DSIM_ERR_INVALID, "dsim_write_traj_line: bad argument");
+  FILE *f = fopen(path, append ? "ab" : "wb");
+  if (!f) return fail(DSIM_ERR_STATE, "cannot open %s", path);
+  int rc = write_traj_lines(f, n_walkers, 1, positions_aos, 0, positions_aos, positions_aos + 1, positions_aos + 2, 3);
+  if (fclose(f) != 0 && rc == DSIM_OK) rc = fail(DSIM_ERR_STATE, "trajectories file: close failed");
+  return rc;
+}
+
+extern "C" int dsim_write_traj(dsim_handle h, const char *path, int32_t t_begin, int32_t t_end, int32_t append) {
+  if (!h || !path) return fail(DSIM_ERR_INVALID, "dsim_write_traj: null argument");
+  int rc = check_recorded_range(h, "dsim_write_traj", t_begin, t_end);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  FILE *f = fopen(path, append ? "ab" : "wb");
+  if (!f) return fail(DSIM_ERR_STATE, "cannot open %s", path);
+  const int64_t n = h->n;
+  if (t_begin < t_end)
+    rc = fetch_recorded(h, t_begin, t_end, [&](int, int cnt, const double *src) {
+      return write_traj_lines(f, n, cnt, src, (size_t)3 * n, src, src + n, src + 2 * n, 1);
+    });
+  if (fclose(f) != 0 && rc == DSIM_OK) rc = fail(DSIM_ERR_STATE, "trajectories file: close failed");
+  return rc;
 }
 
 extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) {

@@ -1,0 +1,171 @@
+/* dsim_unit.hip - TEST-ONLY build (libdsim_unit.so, not part of the product ABI of
+ * include/dsim.h): wrapper kernels that evaluate the per-walker DEVICE functions of
+ * dsim_device.h / dsim_math.h on arrays, one thread per input, so that
+ * tests/test_gpu_device_units.py can compare them on the GPU (i) bit for bit with the CPU
+ * oracle's restatement on millions of random and edge inputs and (ii) with the known
+ * answers of the reference's own wrapper-kernel tests (disimpy/tests/test_simulations.py:23-360).
+ *
+ * The op numbers are shared with dso_ua_eval() in oracle/dsim_oracle.c.  Inputs and outputs
+ * are column arrays of doubles (in[c * n + i]); integers travel as doubles, 64-bit patterns
+ * as the bit pattern of a double.  xs = subvoxel boundaries (ops 8-10).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "dsim_kernels.h"
+
+#define DSU_MAX_COLS 16
+
+struct UnitArgs {
+  int op;
+  long long n;
+  const double *in;
+  double *out;
+  const double *xs;
+  int n_xs;
+};
+
+__global__ __launch_bounds__(256) void unit_kernel(const UnitArgs a) {
+  __shared__ double log_tab[DS_LOG_TABLE_DOUBLES];
+  __shared__ double cos_tab[DS_COS_TABLE_DOUBLES];
+  for (int i = threadIdx.x; i < DS_LOG_TABLE_DOUBLES; i += blockDim.x) log_tab[i] = ds_log_table_dev[i];
+  for (int i = threadIdx.x; i < DS_COS_TABLE_DOUBLES; i += blockDim.x) cos_tab[i] = ds_cos_table_dev[i];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const long long n = a.n;
+#define IN(c) a.in[(long long)(c) * n + i]
+#define OUT(c) a.out[(long long)(c) * n + i]
+  switch (a.op) {
+    case 0: OUT(0) = (double)ds_logf((float)IN(0), log_tab); break;
+    case 1: OUT(0) = ds_cos_0_2pi(IN(0), cos_tab); break;
+    case 2: {
+      double x = IN(0), y = IN(1), z = IN(2);
+      ds_div3(&x, &y, &z, IN(3));
+      OUT(0) = x, OUT(1) = y, OUT(2) = z;
+    } break;
+    case 3: OUT(0) = ds_sqrt_dev(IN(0)); break;
+    case 4: OUT(0) = u64_to_unit_f64((uint64_t)__double_as_longlong(IN(0))); break;
+    case 5: { /* vertices A, B, C; the library pre-gathers {A, B - A, C - A} with these very subtractions */
+      const V3 A = {IN(0), IN(1), IN(2)};
+      const V3 E1 = {IN(3) - A.x, IN(4) - A.y, IN(5) - A.z};
+      const V3 E2 = {IN(6) - A.x, IN(7) - A.y, IN(8) - A.z};
+      const V3 r0 = {IN(9), IN(10), IN(11)}, st = {IN(12), IN(13), IN(14)};
+      OUT(0) = ray_triangle_intersection_check(A, E1, E2, r0, st);
+    } break;
+    case 6:
+    case 7: {
+      V3 r0 = {IN(0), IN(1), IN(2)}, st = {IN(3), IN(4), IN(5)}, nn = {IN(7), IN(8), IN(9)};
+      if (a.op == 6)
+        reflection(r0, st, IN(6), nn, IN(10));
+      else
+        crossing(r0, st, IN(6), nn, IN(10));
+      OUT(0) = r0.x, OUT(1) = r0.y, OUT(2) = r0.z;
+      OUT(3) = st.x, OUT(4) = st.y, OUT(5) = st.z;
+      OUT(6) = nn.x, OUT(7) = nn.y, OUT(8) = nn.z;
+    } break;
+    case 8: {
+      const int ns = a.n_xs - 1;
+      const double inv_h = (double)ns / (a.xs[ns] - a.xs[0]);
+      const double x1 = IN(0), x2 = IN(1);
+      OUT(0) = (double)ll_subvoxel_overlap(a.xs, ns, inv_h, x1 < x2 ? x1 : x2);
+      OUT(1) = (double)ul_subvoxel_overlap(a.xs, ns, inv_h, x1 > x2 ? x1 : x2);
+    } break;
+    case 9:
+    case 10: {
+      const int ns = a.n_xs - 1;
+      const double L = a.xs[ns] - a.xs[0];
+      const double inv_h = (double)ns / L, inv_l = 1.0 / L;
+      if (a.op == 9) {
+        OUT(0) = (double)ll_subvoxel_overlap_periodic(a.xs, ns, inv_h, inv_l, IN(0), IN(1));
+        OUT(1) = (double)ul_subvoxel_overlap_periodic(a.xs, ns, inv_h, inv_l, IN(0), IN(1));
+      } else { /* the loop-free variant of the cooperative kernel: (ll, ul, usable) */
+        int ll = 0, ul = 0;
+        const bool ok = subvoxel_limits_fast(a.xs, ns, a.xs[0], a.xs[ns], inv_h, inv_l, IN(0), IN(1), ll, ul);
+        OUT(0) = (double)ll, OUT(1) = (double)ul, OUT(2) = ok ? 1.0 : 0.0;
+      }
+    } break;
+    case 11: OUT(0) = line_circle_intersection(IN(0), IN(1), IN(2), IN(3), IN(4)); break;
+    case 12: {
+      const V3 r0 = {IN(0), IN(1), IN(2)}, st = {IN(3), IN(4), IN(5)};
+      OUT(0) = line_sphere_intersection(r0, st, IN(6));
+    } break;
+    case 13: {
+      const V3 r0 = {IN(0), IN(1), IN(2)}, st = {IN(3), IN(4), IN(5)};
+      OUT(0) = line_ellipsoid_intersection(r0, st, IN(6), IN(7), IN(8));
+    } break;
+    case 14: {
+      V3 v = {IN(0), IN(1), IN(2)};
+      normalize3(v);
+      OUT(0) = v.x, OUT(1) = v.y, OUT(2) = v.z;
+    } break;
+    case 15: {
+      Rng r = {(uint64_t)__double_as_longlong(IN(0)), (uint64_t)__double_as_longlong(IN(1))};
+      const V3 s = random_step(r, log_tab, cos_tab);
+      OUT(0) = s.x, OUT(1) = s.y, OUT(2) = s.z;
+      OUT(3) = __longlong_as_double((long long)r.s0), OUT(4) = __longlong_as_double((long long)r.s1);
+    } break;
+    case 16: {
+      Rng r = {(uint64_t)__double_as_longlong(IN(0)), (uint64_t)__double_as_longlong(IN(1))};
+      OUT(0) = (double)rng_uniform_f32(r);
+      OUT(1) = rng_uniform_f64(r);
+      OUT(2) = __longlong_as_double((long long)r.s0), OUT(3) = __longlong_as_double((long long)r.s1);
+    } break;
+    case 17: {
+      double R[9];
+      for (int k = 0; k < 9; k++) R[k] = IN(k);
+      const V3 v = {IN(9), IN(10), IN(11)};
+      const V3 o = mat_mul(R, v);
+      OUT(0) = o.x, OUT(1) = o.y, OUT(2) = o.z;
+    } break;
+    case 18: {
+      const V3 p = {IN(0), IN(1), IN(2)}, q = {IN(3), IN(4), IN(5)};
+      const V3 c = cross3(p, q);
+      OUT(0) = dot3(p, q);
+      OUT(1) = c.x, OUT(2) = c.y, OUT(3) = c.z;
+    } break;
+    default: break;
+  }
+#undef IN
+#undef OUT
+}
+
+static std::string g_unit_err;
+extern "C" const char *dsu_last_error(void) { return g_unit_err.c_str(); }
+
+/* in: n_in columns of n doubles (column-major block), out: n_out columns.  Returns 0 or -1. */
+extern "C" int dsu_eval(int op, long long n, int n_in, const double *in, int n_out, double *out, const double *xs, int n_xs) {
+  if (n <= 0 || n_in < 1 || n_in > DSU_MAX_COLS || n_out < 1 || n_out > DSU_MAX_COLS || !in || !out) {
+    g_unit_err = "dsu_eval: bad arguments";
+    return -1;
+  }
+  double *d_in = nullptr, *d_out = nullptr, *d_xs = nullptr;
+  auto fail = [&](const char *what, hipError_t e) {
+    g_unit_err = std::string(what) + ": " + hipGetErrorString(e);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_xs) (void)hipFree(d_xs);
+    return -1;
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&d_in, (size_t)n_in * n * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
+  if ((e = hipMalloc(&d_out, (size_t)n_out * n * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
+  if ((e = hipMemcpy(d_in, in, (size_t)n_in * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+  if ((e = hipMemset(d_out, 0, (size_t)n_out * n * sizeof(double))) != hipSuccess) return fail("hipMemset", e);
+  if (xs && n_xs > 0) {
+    if ((e = hipMalloc(&d_xs, (size_t)n_xs * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemcpy(d_xs, xs, (size_t)n_xs * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+  }
+  UnitArgs a = {op, n, d_in, d_out, d_xs, n_xs};
+  unit_kernel<<<(unsigned)((n + 255) / 256), 256>>>(a);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch", e);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail("sync", e);
+  if ((e = hipMemcpy(out, d_out, (size_t)n_out * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return fail("hipMemcpy", e);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (d_xs) (void)hipFree(d_xs);
+  return 0;
+}

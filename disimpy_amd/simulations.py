@@ -146,7 +146,14 @@ def add_noise_to_data(data, sigma, seed=None):
 
 
 def _write_traj(traj, mode, positions):
-    """Append one line of ``x y z x y z ...`` (shortest round-trip decimals) to the trajectories file."""
+    """One line of ``x y z x y z ...`` (``str(value) + " "`` per coordinate) to the trajectories
+    file (disimpy/simulations.py:1043-1048), formatted by the native writer of the C ABI."""
+    _lib.write_traj_line(traj, positions, append=(mode == "a"))
+
+
+def _write_traj_python(traj, mode, positions):
+    """The reference's own formulation of ``_write_traj`` - kept as the checker of the native writer
+    (tests/test_host_api.py), not used by ``simulation()``."""
     with open(traj, mode) as f:
         f.write(" ".join(map(repr, positions.ravel().tolist())))
         f.write(" \n")
@@ -282,7 +289,7 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             # the trajectories file needs the positions after every step: the device records them
             # and hands them over once per range of steps (<= 64 MB) instead of once per step
             sim.set_recording(True)
-            chunk = max(1, min(n_t, (64 << 20) // (24 * max(1, b - a))))
+            chunk = max(1, min(n_t, (1 << 30) // (24 * max(1, b - a))))  # <= 1 GB of recorded positions per range
         elif quiet:
             chunk = n_t
         else:
@@ -298,8 +305,7 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1)
             ms_total += sim.last_run_ms()[0]
             if traj:
-                for step_positions in sim.recorded(t0, t1):
-                    _write_traj(traj, "a", step_positions)
+                sim.write_traj(traj, t0, t1)
             if not quiet:
                 sys.stdout.write(f"\r{np.round((t0 / n_t) * 100, 1)}%")
                 sys.stdout.flush()

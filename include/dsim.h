@@ -161,6 +161,17 @@ int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches);
 int dsim_set_recording(dsim_handle h, int32_t enable);
 int dsim_get_recorded(dsim_handle h, int32_t t_begin, int32_t t_end, double *out);
 
+/* The trajectories file itself (simulations.py:1043-1048: `str(value) + " "` per coordinate, one
+ * line per time step).  dsim_write_traj appends (append != 0) or writes the lines of steps
+ * [t_begin, t_end) of the last recorded dsim_run_* call to `path`; blocks of steps cross PCIe on
+ * a copy stream of their own into two pinned buffers while host threads format the previous block
+ * (the same double buffering serves dsim_get_recorded).  The text is byte-identical to what the
+ * reference's Python writes: shortest round-trip decimals in CPython's float repr layout.
+ * dsim_write_traj_line writes one such line from a host array (n_walkers,3) - the line of initial
+ * positions that opens the file (:1194); it needs no GPU. */
+int dsim_write_traj(dsim_handle h, const char *path, int32_t t_begin, int32_t t_end, int32_t append);
+int dsim_write_traj_line(const char *path, const double *positions_aos, int64_t n_walkers, int32_t append);
+
 /* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
  * LDS gradient tile, measurements held in registers per pass, and - for mesh
  * substrates - the number of time steps between spatial re-sorts of the walker

@@ -678,3 +678,111 @@ void dso_u_div3(double *v, double length) { ds_div3(&v[0], &v[1], &v[2], length)
 #endif
 double dso_u_cos(double x) { return DSO_COS(x); }
 size_t dso_sizeof_geom(void) { return sizeof(dso_geom); }
+
+/* ---- array form of the unit functions: the CPU side of tests/test_gpu_device_units.py ----
+ * One call evaluates one device function of the reference on n independent inputs (column
+ * arrays in[c][i], results out[c][i]), mirroring disimpy_amd/csrc/dsim_unit.hip op for op so
+ * that the HIP device functions can be compared with this restatement bit for bit on millions
+ * of inputs.  Integer results (subvoxel indices) and raw 64-bit patterns travel as doubles /
+ * as the bit pattern of a double. */
+static inline uint64_t bits_of(double x) {
+  uint64_t b;
+  memcpy(&b, &x, 8);
+  return b;
+}
+static inline double double_of(uint64_t b) {
+  double x;
+  memcpy(&x, &b, 8);
+  return x;
+}
+
+int dso_ua_eval(int op, int64_t n, const double *const *in, double *const *out, const double *xs, int64_t n_xs) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    switch (op) {
+      case 0: out[0][i] = (double)DSO_LOGF((float)in[0][i]); break;
+      case 1: out[0][i] = DSO_COS(in[0][i]); break;
+      case 2: {
+        double v[3] = {in[0][i], in[1][i], in[2][i]};
+#ifdef DSO_SHARED_MATH
+        ds_div3(&v[0], &v[1], &v[2], in[3][i]);
+#else
+        for (int k = 0; k < 3; k++) v[k] = v[k] / in[3][i];
+#endif
+        out[0][i] = v[0], out[1][i] = v[1], out[2][i] = v[2];
+      } break;
+      case 3: out[0][i] = sqrt(in[0][i]); break;
+      case 4: out[0][i] = u64_to_unit_f64(bits_of(in[0][i])); break;
+      case 5: { /* {A, E1, E2} pre-gathered as the library stores them: rebuild B, C is NOT possible exactly, so
+                   the test passes the vertices and this side subtracts like simulations.py:259-262 */
+        double tri[9], r0[3], st[3];
+        for (int k = 0; k < 9; k++) tri[k] = in[k][i];
+        for (int k = 0; k < 3; k++) r0[k] = in[9 + k][i], st[k] = in[12 + k][i];
+        out[0][i] = ray_triangle_intersection_check(tri, r0, st);
+      } break;
+      case 6:
+      case 7: {
+        double r0[3], st[3], nn[3];
+        for (int k = 0; k < 3; k++) r0[k] = in[k][i], st[k] = in[3 + k][i], nn[k] = in[7 + k][i];
+        if (op == 6)
+          reflection(r0, st, in[6][i], nn, in[10][i]);
+        else
+          crossing(r0, st, in[6][i], nn, in[10][i]);
+        for (int k = 0; k < 3; k++) out[k][i] = r0[k], out[3 + k][i] = st[k], out[6 + k][i] = nn[k];
+      } break;
+      case 8:
+        out[0][i] = (double)ll_subvoxel_overlap(xs, n_xs, in[0][i], in[1][i]);
+        out[1][i] = (double)ul_subvoxel_overlap(xs, n_xs, in[0][i], in[1][i]);
+        break;
+      case 9:
+        out[0][i] = (double)ll_subvoxel_overlap_periodic(xs, n_xs, in[0][i], in[1][i]);
+        out[1][i] = (double)ul_subvoxel_overlap_periodic(xs, n_xs, in[0][i], in[1][i]);
+        break;
+      case 11: {
+        double r0[2] = {in[0][i], in[1][i]}, st[2] = {in[2][i], in[3][i]};
+        out[0][i] = line_circle_intersection(r0, st, in[4][i]);
+      } break;
+      case 12: {
+        double r0[3] = {in[0][i], in[1][i], in[2][i]}, st[3] = {in[3][i], in[4][i], in[5][i]};
+        out[0][i] = line_sphere_intersection(r0, st, in[6][i]);
+      } break;
+      case 13: {
+        double r0[3] = {in[0][i], in[1][i], in[2][i]}, st[3] = {in[3][i], in[4][i], in[5][i]};
+        double ax[3] = {in[6][i], in[7][i], in[8][i]};
+        out[0][i] = line_ellipsoid_intersection(r0, st, ax);
+      } break;
+      case 14: {
+        double v[3] = {in[0][i], in[1][i], in[2][i]};
+        normalize3(v);
+        out[0][i] = v[0], out[1][i] = v[1], out[2][i] = v[2];
+      } break;
+      case 15: {
+        dso_state s = {bits_of(in[0][i]), bits_of(in[1][i])};
+        double st[3];
+        random_step(st, &s);
+        out[0][i] = st[0], out[1][i] = st[1], out[2][i] = st[2];
+        out[3][i] = double_of(s.s0), out[4][i] = double_of(s.s1);
+      } break;
+      case 16: {
+        dso_state s = {bits_of(in[0][i]), bits_of(in[1][i])};
+        out[0][i] = (double)uniform_f32(&s);
+        out[1][i] = uniform_f64(&s);
+        out[2][i] = double_of(s.s0), out[3][i] = double_of(s.s1);
+      } break;
+      case 17: {
+        double R[9], v[3] = {in[9][i], in[10][i], in[11][i]};
+        for (int k = 0; k < 9; k++) R[k] = in[k][i];
+        mat_mul(R, v);
+        out[0][i] = v[0], out[1][i] = v[1], out[2][i] = v[2];
+      } break;
+      case 18: {
+        double a[3] = {in[0][i], in[1][i], in[2][i]}, b[3] = {in[3][i], in[4][i], in[5][i]}, c[3];
+        cross3(a, b, c);
+        out[0][i] = dot3(a, b);
+        out[1][i] = c[0], out[2][i] = c[1], out[3][i] = c[2];
+      } break;
+      default: break;
+    }
+  }
+  return (op >= 0 && op <= 18 && op != 10) ? 0 : -1;
+}
