@@ -17,7 +17,7 @@ SYMBOLS = (
     "dsim_create", "dsim_destroy", "dsim_set_positions", "dsim_set_rng_states", "dsim_set_mesh",
     "dsim_run_free", "dsim_run_sphere", "dsim_run_cylinder", "dsim_run_ellipsoid", "dsim_run_mesh",
     "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
-    "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
+    "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
     "dsim_write_traj", "dsim_write_traj_line",
 )  # fmt: skip
@@ -71,6 +71,8 @@ def load():
                                    _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, _f64p]
     lib.dsim_mesh_subdivide.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p,
                                         _i64p]
+    lib.dsim_mesh_clearance_map.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, C.c_double,
+                                            _i32p, C.POINTER(C.c_uint32), _i64p, _i32p]
     lib.dsim_triangle_box_overlap.argtypes = [_f64p, _f64p]
     lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
     lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
@@ -133,6 +135,25 @@ def mesh_subdivide(vertices, faces, xs, ys, zs, n_sv):
     check(lib.dsim_mesh_subdivide(p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv),
                                   p_i64(svi), p_i64(tri) if len(tri) else None, C.byref(n_refs)))
     return tri, svi
+
+
+def mesh_clearance_map(vertices, faces, xs, ys, zs, n_sv, step_l):
+    """The walk kernel's clearance map: (clear_idx (prod n_sv,) int32, bits uint32, F) or None when no map is used."""
+    lib = load()
+    v, f = _c(vertices, np.float64), _c(faces, np.int64)
+    xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+    nsv = _c(n_sv, np.int64)
+    n_words, lf = C.c_int64(0), C.c_int32(0)
+    check(lib.dsim_mesh_clearance_map(p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv),
+                                      step_l, None, None, C.byref(n_words), C.byref(lf)))
+    if n_words.value == 0:
+        return None
+    idx = np.zeros(int(np.prod(nsv)), dtype=np.int32)
+    bits = np.zeros(n_words.value, dtype=np.uint32)
+    check(lib.dsim_mesh_clearance_map(p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv),
+                                      step_l, idx.ctypes.data_as(_i32p), bits.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      C.byref(n_words), C.byref(lf)))
+    return idx, bits, 1 << lf.value
 
 
 def triangle_box_overlap(triangle, box):

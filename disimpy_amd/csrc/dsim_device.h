@@ -293,6 +293,17 @@ DSD bool subvoxel_limits_fast(const double *xs, int n, double lo, double hi, dou
   return (!in_min || (a <= smin && smin < b)) && (!in_max || (c < smax && smax <= d));
 }
 
+/* fine-cell coordinate of x on one axis of the clearance map: position inside the periodic voxel
+ * (any image) times cells per voxel, clamped.  A rounding error here moves a walker that sits within
+ * ~1e-12 m of a cell face into the neighbouring cell; the map is built with a margin of 1e-3 cell
+ * sizes for exactly that. */
+DSD int clearance_cell(double x, double inv_l, int n_fine) {
+  double f = x * inv_l;
+  f -= __builtin_floor(f);
+  int i = (int)(f * (double)n_fine);
+  return i < 0 ? 0 : (i > n_fine - 1 ? n_fine - 1 : i);
+}
+
 /* floor division for the periodic image index (Python: math.floor(x / n)) */
 DSD int floor_div(int x, int n) {
   int q = x / n;

@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
@@ -15,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -203,6 +205,10 @@ struct DevMesh {
   float4 *mrec = nullptr;
   float4 *tri_yz = nullptr;
   int2 *sv_micro = nullptr, *cell_range = nullptr;
+  int32_t *clear_idx = nullptr;
+  uint32_t *clear_bits = nullptr;
+  int clear_lf = 0;
+  double clear_frac = 0; /* share of the voxel's fine cells that are clear (diagnostic) */
   double *bounds = nullptr;
   int nx = 0, ny = 0, nz = 0;
   double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
@@ -238,7 +244,9 @@ struct dsim_sim {
   int block_size = 256, tile_steps = 0, meas_per_pass = 0;
   int resort_steps = 0; /* mesh: 0 = automatic, < 0 = never re-sort the walkers */
   int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
-  int mesh_traversal = 0; /* 0/2 = wavefront-cooperative, 1 = per-lane */
+  int mesh_traversal = 0; /* 0/2 = wavefront-cooperative (clearance map when it pays), 1 = per-lane, 3 = cooperative, never the map, 4 = always */
+  unsigned long long *clear_count = nullptr;
+  double last_clear_frac = 0;
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
   bool sort_ready = false;
   double *phase_alt = nullptr;
@@ -268,6 +276,8 @@ static void free_mesh(DevMesh &m) {
   if (m.tri_yz) (void)hipFree(m.tri_yz);
   if (m.sv_micro) (void)hipFree(m.sv_micro);
   if (m.cell_range) (void)hipFree(m.cell_range);
+  if (m.clear_idx) (void)hipFree(m.clear_idx);
+  if (m.clear_bits) (void)hipFree(m.clear_bits);
   if (m.bounds) (void)hipFree(m.bounds);
   m = DevMesh();
 }
@@ -275,6 +285,7 @@ static void free_mesh(DevMesh &m) {
 static int ensure_staging(dsim_sim *h, size_t bytes) {
   if (h->staging_bytes >= bytes) return DSIM_OK;
   if (h->staging) (void)hipFree(h->staging);
+  if (h->clear_count) (void)hipFree(h->clear_count);
   h->staging = nullptr;
   h->staging_bytes = 0;
   HIP_TRY(hipMalloc(&h->staging, bytes));
@@ -410,7 +421,7 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
 #endif
     h->grad_src = gradient_source - 1;
   }
-  if (mesh_traversal == 1 || mesh_traversal == 2) h->mesh_traversal = mesh_traversal;
+  if (mesh_traversal >= 1 && mesh_traversal <= 4) h->mesh_traversal = mesh_traversal;
   return DSIM_OK;
 }
 
@@ -572,6 +583,154 @@ static bool triangle_reaches_cell(const double *const tv[3], const float *tlo, c
   return true;
 }
 
+/* Triangle (v0, v1, v2) against the axis-aligned box of centre c and half-widths h: separating-axis
+ * test (Akenine-Moller), in double precision on coordinates relative to the box centre.  Used with boxes
+ * already inflated by far more than its own rounding, so "false" is certain. */
+static bool triangle_meets_box(const double *v0, const double *v1, const double *v2, const double c[3], const double h[3]) {
+  double v[3][3], e[3][3];
+  for (int ax = 0; ax < 3; ax++) {
+    v[0][ax] = v0[ax] - c[ax];
+    v[1][ax] = v1[ax] - c[ax];
+    v[2][ax] = v2[ax] - c[ax];
+  }
+  for (int ax = 0; ax < 3; ax++) {
+    const double mn = std::min(v[0][ax], std::min(v[1][ax], v[2][ax])), mx = std::max(v[0][ax], std::max(v[1][ax], v[2][ax]));
+    if (mn > h[ax] || mx < -h[ax]) return false;
+  }
+  for (int ax = 0; ax < 3; ax++) {
+    e[0][ax] = v[1][ax] - v[0][ax];
+    e[1][ax] = v[2][ax] - v[1][ax];
+    e[2][ax] = v[0][ax] - v[2][ax];
+  }
+  for (int j = 0; j < 3; j++)
+    for (int ax = 0; ax < 3; ax++) {
+      const int u = (ax + 1) % 3, w = (ax + 2) % 3;
+      const double au = -e[j][w], aw = e[j][u]; /* unit_ax x e_j */
+      const double p0 = au * v[0][u] + aw * v[0][w], p1 = au * v[1][u] + aw * v[1][w], p2 = au * v[2][u] + aw * v[2][w];
+      const double r = h[u] * std::fabs(au) + h[w] * std::fabs(aw);
+      if (std::min(p0, std::min(p1, p2)) > r || std::max(p0, std::max(p1, p2)) < -r) return false;
+    }
+  const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+  const double d = n[0] * v[0][0] + n[1] * v[0][1] + n[2] * v[0][2];
+  const double r = h[0] * std::fabs(n[0]) + h[1] * std::fabs(n[1]) + h[2] * std::fabs(n[2]);
+  return std::fabs(d) <= r;
+}
+
+/* Clearance map.  The reference's reflect loop (simulations.py:924-997) ends a time step without a
+ * reflection - and without drawing from the RNG - whenever no triangle is met within the step length:
+ * `min_d > step_l`.  For a walker farther than step_l from EVERY triangle that is certain before any
+ * look-up.  The map makes that test one bit: every subvoxel is cut into F^3 fine cells (F a power of two
+ * <= 16, cells not smaller than half a step); a cell's bit is set when some triangle - in any periodic
+ * image: the reference's look-ups wrap around the voxel whatever `periodic` says - meets the cell's box
+ * inflated on all sides by
+ *     reach = step_l * (1 + 1e-6)    (a hit at fp64 distance d <= step_l lies within that of the start)
+ *           + 2e-3 * cell size       (the kernel's cell assignment near a face; rounding of this test).
+ * The cube contains the ball, so a clear bit proves `min_d > step_l` for every walker in the cell and
+ * every direction; a set bit proves nothing and the walker takes the full pass.  Results are therefore
+ * bit-identical with and without the map (tests/test_gpu_production.py compares against the oracle,
+ * which knows nothing of it). */
+static void build_clearance_map(const double *vertices, const int64_t *faces, int64_t n_faces, const double *const b3[3],
+                                const int64_t n_sv[3], double step_l, std::vector<int32_t> &clear_idx,
+                                std::vector<uint32_t> &clear_bits, int &lf_out, double &clear_frac) {
+  clear_idx.clear();
+  clear_bits.clear();
+  lf_out = 0;
+  clear_frac = 0;
+  double L[3], hsub_min = 1e300;
+  for (int k = 0; k < 3; k++) {
+    L[k] = b3[k][n_sv[k]] - b3[k][0];
+    if (!(L[k] > 0) || !std::isfinite(L[k])) return;
+    hsub_min = std::min(hsub_min, L[k] / (double)n_sv[k]);
+  }
+  if (!(step_l >= 0) || !std::isfinite(step_l)) return;
+  const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
+  int lf = 4;
+  while (lf > 0 && hsub_min / (double)(1 << lf) < 0.5 * step_l) lf--;
+  while (lf > 0 && (double)n_sub * (double)(1 << (3 * lf)) / 8.0 > 768e6) lf--; /* dense scratch bitmap <= 768 MB */
+  if ((double)n_sub * (double)(1 << (3 * lf)) / 8.0 > 768e6) return;
+  const int F = 1 << lf;
+  const size_t words = (size_t)std::max(1, (F * F * F) >> 5);
+  double hf[3], reach[3];
+  int64_t nf[3];
+  for (int k = 0; k < 3; k++) {
+    nf[k] = n_sv[k] * F;
+    hf[k] = L[k] / (double)nf[k];
+    reach[k] = step_l * (1.0 + 1e-6) + 2e-3 * hf[k];
+  }
+  /* work estimate: cells in the inflated bounding boxes; a mesh of huge triangles on a fine grid is not worth it */
+  double work = 0;
+  for (int64_t f = 0; f < n_faces; f++) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++) {
+      const double a = vertices[faces[f * 3] * 3 + k], b = vertices[faces[f * 3 + 1] * 3 + k], c = vertices[faces[f * 3 + 2] * 3 + k];
+      const double ext = std::max(a, std::max(b, c)) - std::min(a, std::min(b, c)) + 2 * reach[k];
+      cells *= std::floor(ext / hf[k]) + 3;
+    }
+    work += cells;
+  }
+  if (work > 4e9) return;
+  std::unique_ptr<std::atomic<uint32_t>[]> dense(new std::atomic<uint32_t>[(size_t)n_sub * words]());
+  const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n_faces / 64));
+  std::atomic<int64_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const int64_t f0 = next.fetch_add(64);
+      if (f0 >= n_faces) break;
+      for (int64_t f = f0; f < std::min(n_faces, f0 + 64); f++) {
+        const double *v0 = &vertices[faces[f * 3] * 3], *v1 = &vertices[faces[f * 3 + 1] * 3], *v2 = &vertices[faces[f * 3 + 2] * 3];
+        int64_t lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+          const double mn = std::min(v0[k], std::min(v1[k], v2[k])) - reach[k], mx = std::max(v0[k], std::max(v1[k], v2[k])) + reach[k];
+          /* one cell of slack: the SAT test decides.  A range longer than the axis visits a wrapped cell through
+           * several of its images - each has to be tested, the triangle may reach only one of them */
+          lo[k] = (int64_t)std::floor((mn - b3[k][0]) / hf[k]) - 1;
+          hi[k] = (int64_t)std::floor((mx - b3[k][0]) / hf[k]) + 1;
+        }
+        for (int64_t i = lo[0]; i <= hi[0]; i++)
+          for (int64_t j = lo[1]; j <= hi[1]; j++)
+            for (int64_t k = lo[2]; k <= hi[2]; k++) {
+              const int64_t ijk[3] = {i, j, k};
+              double c[3], h[3];
+              int64_t w[3];
+              for (int a = 0; a < 3; a++) {
+                c[a] = b3[a][0] + ((double)ijk[a] + 0.5) * hf[a]; /* the image cell, in the triangle's frame */
+                h[a] = 0.5 * hf[a] + reach[a];
+                w[a] = ((ijk[a] % nf[a]) + nf[a]) % nf[a];
+              }
+              if (!triangle_meets_box(v0, v1, v2, c, h)) continue;
+              const int64_t sv = ((w[0] >> lf) * n_sv[1] + (w[1] >> lf)) * n_sv[2] + (w[2] >> lf);
+              const unsigned bit = (unsigned)(((((w[0] & (F - 1)) << lf) | (w[1] & (F - 1))) << lf) | (w[2] & (F - 1)));
+              dense[(size_t)sv * words + (bit >> 5)].fetch_or(1u << (bit & 31), std::memory_order_relaxed);
+            }
+      }
+    }
+  };
+  if (n_thr <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n_thr; t++) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+  }
+  clear_idx.assign((size_t)n_sub, -1);
+  const uint32_t used_mask = F * F * F >= 32 ? 0xffffffffu : ((1u << (F * F * F)) - 1u);
+  double set_bits = 0;
+  for (int64_t s = 0; s < n_sub; s++) {
+    bool any = false;
+    for (size_t w = 0; w < words; w++) any |= (dense[(size_t)s * words + w].load(std::memory_order_relaxed) & used_mask) != 0;
+    if (!any) continue;
+    clear_idx[(size_t)s] = (int32_t)(clear_bits.size() / words);
+    for (size_t w = 0; w < words; w++) {
+      const uint32_t v = dense[(size_t)s * words + w].load(std::memory_order_relaxed);
+      clear_bits.push_back(v);
+      set_bits += __builtin_popcount(v & used_mask);
+    }
+  }
+  if (clear_bits.empty()) clear_bits.push_back(0u);
+  lf_out = lf;
+  clear_frac = 1.0 - set_bits / ((double)n_sub * F * F * F);
+}
+
 static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
                        int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                        const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l) {
@@ -729,6 +888,19 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
   bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
   bounds.insert(bounds.end(), zs, zs + n_sv[2] + 1);
+  if (step_l > 0) { /* the walk's clearance map (not used by the fill kernel, which passes step_l = 0) */
+    std::vector<int32_t> cidx;
+    std::vector<uint32_t> cbits;
+    const double *bb[3] = {xs, ys, zs};
+    build_clearance_map(vertices, faces, n_faces, bb, n_sv, step_l, cidx, cbits, dm.clear_lf, dm.clear_frac);
+    if (!cidx.empty()) {
+      HIP_TRY(hipMalloc(&dm.clear_idx, cidx.size() * sizeof(int32_t)));
+      HIP_TRY(hipMalloc(&dm.clear_bits, cbits.size() * sizeof(uint32_t)));
+      HIP_TRY(hipMemcpyAsync(dm.clear_idx, cidx.data(), cidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(dm.clear_bits, cbits.data(), cbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipStreamSynchronize(stream)); /* the host vectors die with this scope */
+    }
+  }
   HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
@@ -771,6 +943,9 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.sv_micro = dm.sv_micro;
   m.cell_range = dm.cell_range;
   m.bounds = dm.bounds;
+  m.clear_idx = dm.clear_idx;
+  m.clear_bits = dm.clear_bits;
+  m.clear_lf = dm.clear_lf;
   m.nx = dm.nx;
   m.ny = dm.ny;
   m.nz = dm.nz;
@@ -783,6 +958,33 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.x0 = dm.lo[0], m.y0 = dm.lo[1], m.z0 = dm.lo[2];
   m.x1 = dm.hi[0], m.y1 = dm.hi[1], m.z1 = dm.hi[2];
   return m;
+}
+
+extern "C" int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
+                                       const double *ys, const double *zs, const int64_t n_sv[3], double step_l, int32_t *clear_idx,
+                                       uint32_t *clear_bits, int64_t *n_words, int32_t *log2_cells) {
+  if (!vertices || !faces || !xs || !ys || !zs || !n_sv || !n_words || !log2_cells) return fail(DSIM_ERR_INVALID, "dsim_mesh_clearance_map: null argument");
+  for (int64_t i = 0; i < n_faces * 3; i++)
+    if (faces[i] < 0 || faces[i] >= n_vertices) return fail(DSIM_ERR_INVALID, "dsim_mesh_clearance_map: face out of range");
+  std::vector<int32_t> cidx;
+  std::vector<uint32_t> cbits;
+  int lf = 0;
+  double frac = 0;
+  const double *bb[3] = {xs, ys, zs};
+  build_clearance_map(vertices, faces, n_faces, bb, n_sv, step_l, cidx, cbits, lf, frac);
+  if (cidx.empty()) { /* no map for this mesh / step length: nothing is ever skipped */
+    *n_words = 0;
+    *log2_cells = -1;
+    return DSIM_OK;
+  }
+  if (clear_idx && clear_bits) {
+    if (*n_words < (int64_t)cbits.size()) return fail(DSIM_ERR_INVALID, "dsim_mesh_clearance_map: clear_bits too small");
+    memcpy(clear_idx, cidx.data(), cidx.size() * sizeof(int32_t));
+    memcpy(clear_bits, cbits.data(), cbits.size() * sizeof(uint32_t));
+  }
+  *n_words = (int64_t)cbits.size();
+  *log2_cells = lf;
+  return DSIM_OK;
 }
 
 extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
@@ -919,6 +1121,18 @@ static int restore_walker_order(dsim_sim *h) {
   return DSIM_OK;
 }
 
+/* how many walkers currently sit in a clear cell of the clearance map */
+__global__ void clear_count_kernel(const double *x, const double *y, const double *z, int64_t n, const MeshDev ms, unsigned long long *count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool c = false;
+  if (i < n) {
+    const V3 r = {x[i], y[i], z[i]};
+    c = walker_is_clear(ms, r);
+  }
+  const unsigned long long m = __ballot(c);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
 static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_t t_end) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (t_begin < 0 || t_end > h->T || t_begin > t_end) return fail(DSIM_ERR_INVALID, "time range [%d, %d) outside [0, %d)", t_begin, t_end, h->T);
@@ -1025,6 +1239,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       steps = std::max(16, steps / 2);
     }
   }
+  /* clearance map: mesh_traversal 2 = decide per launch, 4 = always, 3 (and the per-lane traversal) = never */
+  const MeshDev clear_map = p.mesh;
+  const bool clear_forced = h->mesh_traversal == 4;
+  if (geom != GEOM_MESH || !coop || h->mesh_traversal == 3) p.mesh.clear_idx = nullptr;
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   bool permuted = false;
   /* the time loop; any failure inside leaves through `return`, and the walker order is put back
@@ -1036,6 +1254,21 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       int rc = resort_walkers(h, !permuted);
       if (rc) return rc;
       permuted = true;
+    }
+    if (clear_map.clear_idx && !clear_forced) {
+      /* The map pays when whole wavefronts are clear (they then run at the cost of free diffusion); with a
+       * minority of clear walkers scattered over the wavefronts its two look-ups per step cost more than the
+       * skipped passes save (neuron, walkers inside: 21 % clear, -1.5 %).  Decide per launch from the share
+       * of walkers that are clear right now - results do not depend on the choice. */
+      if (!h->clear_count) HIP_TRY(hipMalloc(&h->clear_count, sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(h->clear_count, 0, sizeof(unsigned long long), h->stream));
+      clear_count_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->x[h->cur], h->y[h->cur], h->z[h->cur], h->n, clear_map, h->clear_count);
+      HIP_TRY(hipGetLastError());
+      unsigned long long cnt = 0;
+      HIP_TRY(hipMemcpyAsync(&cnt, h->clear_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      h->last_clear_frac = (double)cnt / (double)h->n;
+      p.mesh.clear_idx = h->last_clear_frac >= 0.4 ? clear_map.clear_idx : nullptr;
     }
    for (int ta = ca; ta < cb;) {
     const int tb = record ? std::min(cb, ta + h->traj_steps) : cb; /* recording: traj_steps covers the whole range */

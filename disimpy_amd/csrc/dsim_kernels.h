@@ -75,6 +75,13 @@ struct MeshDev {
                               position in the reference's list */
   const float4 *tri_yz;    /* [n_faces]     {miny minz maxy maxz} float32, rounded outward (fill kernel) */
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
+  /* clearance map (dsim_hip.hip, build_clearance_map): every subvoxel is cut into F^3 fine cells, F = 1 << clear_lf;
+   * a set bit = some triangle (of any periodic image) comes within one step length (+ margins) of some point of
+   * that cell.  clear_idx[sv] = -1: no bit set in the whole subvoxel, else the subvoxel's block of
+   * max(1, F^3 / 32) dwords in clear_bits.  nullptr = no map (every walker takes the full pass). */
+  const int32_t *clear_idx;
+  const uint32_t *clear_bits;
+  int clear_lf;
   int nx, ny, nz;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
   double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
@@ -452,7 +459,7 @@ DSD void walk_body(const WalkParams &p) {
       }
 #endif
       int k_lane = 0;
-      bool in_step = false;
+      bool in_step = false, clear = false;
       V3 step = {0, 0, 0};
       double sl = 0;
       int64_t iter_idx = 0;
@@ -460,13 +467,15 @@ DSD void walk_body(const WalkParams &p) {
         const bool want = live && k_lane < kt;
         if (__ballot(want) == 0ULL) break;
         if (want && !in_step) {
+          clear = walker_is_clear(p.mesh, r); /* look-ups issued before, consumed after the random step */
           step = random_step(rng, log_tab, cos_tab);
           sl = p.step_l;
           iter_idx = 0;
           in_step = true;
         }
         T_MARK(coop, lane, 0);
-        const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, p, xs, ys, zs, rng, coop, lane);
+        const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, clear, p, xs, ys, zs, rng, coop, lane);
+        clear = false; /* only the first pass of a step starts a full step length away from its start */
         if (in_step && finished) {
           if (iter_idx >= p.max_iter) exc = true; /* simulations.py:999-1002 */
           r.x = __builtin_fma(step.x, sl, r.x);

@@ -150,6 +150,20 @@ DSD bool cull_record(const float4 &q0, const float4 &q1, const float4 &q2, const
   return (s0 > cb.tau && s1 > cb.tau) || (s0 < -cb.tau && s1 < -cb.tau);
 }
 
+/* the same decision as cull_record() as ONE number, without branches or mask arithmetic: > 0 when the record
+ * can be skipped.  max over (a) the six box gaps - a positive gap on any axis separates the triangle's box from
+ * the segment's - and (b) how far beyond the margin tau BOTH end points lie on one side of the triangle's
+ * plane.  Every rounding / flush-to-zero / NaN case falls on the "keep" side or concerns a walker whose fp64
+ * test cannot hit anyway. */
+DSD float cull_margin(const float4 &q0, const float4 &q1, const float4 &q2, const CullBox &cb) {
+  const float g1 = __builtin_fmaxf(__builtin_fmaxf(q0.x - cb.hix, q0.y - cb.hiy), q0.z - cb.hiz);
+  const float g2 = __builtin_fmaxf(__builtin_fmaxf(cb.lox - q0.w, cb.loy - q1.x), cb.loz - q1.y);
+  const float s0 = __builtin_fmaf(q2.x, cb.az, __builtin_fmaf(q1.z, cb.ax, q1.w * cb.ay)) - q2.y;
+  const float s1 = __builtin_fmaf(q2.x, cb.ez, __builtin_fmaf(q1.z, cb.ex, q1.w * cb.ey)) - q2.y;
+  const float side = __builtin_fmaxf(__builtin_fminf(s0, s1) - cb.tau, -__builtin_fmaxf(s0, s1) - cb.tau);
+  return __builtin_fmaxf(__builtin_fmaxf(g1, g2), side);
+}
+
 struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
   int llx, lly, llz, ulx, uly, ulz;
 };
@@ -323,6 +337,24 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   T_MARK(W, lane, 6);
 }
 
+/* Is the walker farther than one step length from every triangle (clearance map, MeshDev)?  Then the
+ * first pass of its reflect loop cannot find a hit (`min_d > step_l`, simulations.py:986) and the whole
+ * traversal is skipped.  Two dependent 4-byte look-ups; called before the random step is drawn so that
+ * their latency hides behind it. */
+DSD bool walker_is_clear(const MeshDev &ms, const V3 &r) {
+  if (ms.clear_idx == nullptr) return false;
+  const int lf = ms.clear_lf, m = (1 << lf) - 1;
+  const int ix = clearance_cell(r.x - ms.x0, ms.inv_lx, ms.nx << lf);
+  const int iy = clearance_cell(r.y - ms.y0, ms.inv_ly, ms.ny << lf);
+  const int iz = clearance_cell(r.z - ms.z0, ms.inv_lz, ms.nz << lf);
+  const int blk = ms.clear_idx[((ix >> lf) * ms.ny + (iy >> lf)) * ms.nz + (iz >> lf)];
+  if (blk < 0) return true; /* nothing within reach of the whole subvoxel */
+  const unsigned bit = (unsigned)(((((ix & m) << lf) | (iy & m)) << lf) | (iz & m));
+  const unsigned words = lf >= 2 ? 1u << (3 * lf - 5) : 1u;
+  const uint32_t w = ms.clear_bits[(size_t)blk * words + (bit >> 5)];
+  return ((w >> (bit & 31u)) & 1u) == 0u;
+}
+
 /* ONE pass of the reflect loop of simulations.py:924-997 for the 64 walkers of a wavefront
  * together.  EVERY lane of the wavefront must call this; in_step marks the lanes whose walker
  * is inside a time step.  Returns true for the lanes whose step is over after this pass (no
@@ -330,14 +362,21 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
  * no longer holds).  The caller lets every lane run through its own time steps at its own pace
  * (a wavefront then needs about mean-iterations-per-step passes per step, not the maximum over
  * its 64 lanes). */
-DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, const WalkParams &p, const double *xs,
-                        const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
+DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, bool clear, const WalkParams &p,
+                        const double *xs, const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
   const MeshDev &ms = p.mesh;
   const int ny = ms.ny, nz = ms.nz;
   const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1; /* = xs[nx], ys[ny], zs[nz] */
   bool finished = false;
-  const bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
+  bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
   if (in_step && !act) finished = true; /* while-condition false on entry */
+  if (act && clear) {
+    /* no triangle within the step length (clearance map): this pass of the loop finds min_d > step_l
+     * whatever the direction (simulations.py:986-987) - counted, but not traversed */
+    iter_idx++;
+    finished = true;
+    act = false;
+  }
   if (__ballot(act) == 0ULL) return finished;
   if (lane == 0) {
     W->n_surv = 0;
@@ -516,16 +555,26 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           q1[u] = ms.mrec[3 * j + 1];
           q2[u] = ms.mrec[3 * j + 2];
         }
+        /* the four tests without a branch between them (the plane test used to sit behind the box test, but
+         * with 64 lanes x 4 records somebody always passes the box, so the branch only cost mask juggling);
+         * one LDS atomic per lane reserves the slots of all its survivors */
+        unsigned alive = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (u < cnt && !cull_record(q0[u], q1[u], q2[u], cb) && !ABLATE(3) && !ABLATE(4)) {
-            const int slot = atomicAdd(&W->n_surv, 1);
+        for (int u = 0; u < 4; u++) alive |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
+        alive &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
+        if (ABLATE(3) || ABLATE(4)) alive = 0;
+        if (alive) {
+          int slot = atomicAdd(&W->n_surv, (int)__builtin_popcount(alive));
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (!(alive >> u & 1u)) continue;
             if (slot < COOP_SURV_CAP) {
               W->surv_tri[slot] = (unsigned)__float_as_int(q2[u].z);
               W->surv_pos[slot] = (unsigned)__float_as_int(q2[u].w);
               W->surv_tag[slot] = it.y;
             } else
               W->overflow[owner] = 1;
+            slot++;
           }
         }
         }

@@ -15,6 +15,23 @@
  * (M,N) float64, gradient components (M,T) float64 each, RNG states
  * {uint64 s0, uint64 s1} per walker, mesh index arrays int64.  Inside the
  * library everything is re-laid-out SoA for coalesced HBM access.
+ *
+ * Hard limits (every one fails loudly with DSIM_ERR_INVALID / DSIM_ERR_STATE and a message,
+ * none silently changes results):
+ *   - walker indices: first_walker + n_walkers < 2^47 (depth of the RNG jump tables);
+ *   - mesh: n_faces, n_refs and prod(n_sv) < 2^31, every n_sv[k] in [1, 4096]; the
+ *     wavefront-cooperative traversal packs subvoxel coordinates in 10 bits, so with an
+ *     n_sv[k] > 1024 every pass is done by the slower serial per-walker path (same results);
+ *     the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
+ *     i.e. n_sv[0] + n_sv[1] + n_sv[2] below about 14 000;
+ *   - spatial re-sorting of the walker slots (mesh substrates) needs 4096 <= n_walkers < 2^31
+ *     per handle; outside that range the run proceeds unsorted (slower, same results);
+ *   - recording (dsim_set_recording): the range of one dsim_run_* call must fit 32 GB of
+ *     positions (24 bytes per walker and step); M > 32 or mesh runs with M > 2 record
+ *     internally and cut their launches to what the device can spare instead;
+ *   - dsim_fill_mesh: n_points < 2^31, and a sample that meets 1000 distinct triangles is
+ *     abandoned like in the reference (simulations.py:478-479);
+ *   - gradient: M >= 1, T >= 1, T * M * 32 bytes of device memory for the re-laid-out waveform.
  */
 #ifndef DSIM_H
 #define DSIM_H
@@ -133,6 +150,20 @@ int dsim_mesh_subdivide(const double *vertices, int64_t n_vertices, const int64_
                         const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                         int64_t *subvoxel_indices, int64_t *triangle_indices, int64_t *n_refs);
 
+/* The clearance map dsim_set_mesh builds for the walk kernel, exported for tests (needs no GPU).
+ * The reference's reflect loop ends a step without reflection and without an RNG draw when no
+ * triangle is met within the step length (`min_d > step_l`, simulations.py:986-987); a walker farther
+ * than step_l from every triangle (of every periodic image) can skip the look-ups that establish
+ * this.  Every subvoxel is cut into F^3 cells, F = 1 << *log2_cells; bit ((a * F + b) * F + c) of a
+ * subvoxel's block of max(1, F^3 / 32) words is SET when some triangle meets cell (a, b, c) inflated
+ * by step_l * (1 + 1e-6) + 2e-3 cell sizes.  clear_idx[sv] = -1 (whole subvoxel clear) or the block
+ * number.  Call with clear_idx == NULL to get *n_words (0: no map is used for this input), then
+ * again with buffers of prod(n_sv) int32 and *n_words uint32. */
+int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                            const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                            double step_l, int32_t *clear_idx, uint32_t *clear_bits, int64_t *n_words,
+                            int32_t *log2_cells);
+
 /* The two predicates dsim_mesh_subdivide is built from, exported for unit tests
  * that mirror disimpy/tests/test_substrates.py:293-345: triangle (3,3) vs box
  * (2,3) overlap (substrates.py:291-368; returns 1/0), and the subvoxel index
@@ -177,8 +208,10 @@ int dsim_write_traj_line(const char *path, const double *positions_aos, int64_t 
  * substrates - the number of time steps between spatial re-sorts of the walker
  * slots (0 = automatic, negative = never), and where the kernels read the
  * gradient samples from (1 = LDS tiles, 2 = scalar loads), how the mesh index is
- * traversed (1 = per lane, 2 = wavefront-cooperative).  Results never depend on
- * any of them. */
+ * traversed (1 = per lane, 2 = wavefront-cooperative, using the clearance map -
+ * walkers farther than a step from every triangle skip the traversal - in the
+ * launches that start with >= 40 % of the walkers clear; 3 = never, 4 = always
+ * the map).  Results never depend on any of them. */
 int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass,
                     int32_t resort_steps, int32_t gradient_source, int32_t mesh_traversal);
 

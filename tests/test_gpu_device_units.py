@@ -84,19 +84,20 @@ def _vecs(rng, n, k=3, scale=1.0):
 # ------------------------------------------------------------------ dsim_math.h on the device
 
 
-def test_logf_on_device_equals_host_and_is_within_one_ulp_of_libm(dev, host, oracle_libm):
+def test_logf_on_device_equals_host_and_is_correctly_rounded(dev, host):
     rng = np.random.RandomState(1)
     u = (rng.randint(0, 2**53, N).astype(np.float64) * 2.0**-53).astype(np.float32)  # the uniforms Box-Muller sees
-    edge = np.array([0.0, 2.0**-149, 2.0**-126, 2.0**-24, 0.5, np.nextafter(np.float32(1), np.float32(0)), 1.0, 1.5,
-                     3.0e38, np.inf], dtype=np.float32)
+    edge = np.array([0.0, 2.0**-149, 2.0**-126, 2.0**-53, 2.0**-24, 0.5, np.nextafter(np.float32(1), np.float32(0)), 1.0,
+                     1.5, 3.0e38, np.inf], dtype=np.float32)
     x = np.concatenate([u, edge, np.float32(2.0) ** rng.randint(-149, 128, 4096).astype(np.float32) *
-                        (1 + rng.random_sample(4096).astype(np.float32))]).astype(np.float64)
+                        (1 + rng.random_sample(4096).astype(np.float32))]).astype(np.float32).astype(np.float64)
     got, want = dev(0, [x], 1)[0], host(0, [x], 1)[0]
     assert _same_bits(got, want)
-    fin = np.isfinite(x) & (x > 0)
-    libm = np.log(x[fin].astype(np.float32)).astype(np.float64)  # correctly rounded in practice
-    ulp = np.spacing(np.abs(libm).astype(np.float32)).astype(np.float64)
-    assert np.all(np.abs(got[fin] - libm) <= ulp)
+    # normal float32 arguments (the uniforms are 0 or >= 2^-53): the float64 logarithm rounded once to float32,
+    # i.e. the correctly rounded logf - what CUDA's libdevice returns on all but ~1e-7 of the inputs
+    nrm = np.isfinite(x) & (x >= 2.0**-126)
+    npt.assert_array_equal(got[nrm], np.log(x[nrm]).astype(np.float32).astype(np.float64))
+    assert got[x == 0][0] == -np.inf  # u1 == 0: the reference does not guard it either
 
 
 def test_cos_on_device_equals_host(dev, host):

@@ -82,7 +82,9 @@ def test_c4_packed_cylinders_bit_identical(lib, oracle_exact):
     ma = _mesh_arrays(sub)
     ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
     kw = dict(max_iter=1000, epsilon=1e-13)
-    for tuning in (None, dict(resort_steps=128)):
+    # default tuning; frequent re-sorts; the clearance map forced on (walkers farther than a step from every
+    # triangle skip the traversal: every triangle of this mesh spans the whole periodic z axis)
+    for tuning in (None, dict(resort_steps=128), dict(mesh_traversal=4), dict(mesh_traversal=3)):
         gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma, tuning=tuning)
         _assert_identical(gpu, ref)
     # walkers that start inside a cylinder stay inside it (mesh() moved the lattice: take the axes from
@@ -113,8 +115,34 @@ def test_c5b_refined_neuron_bit_identical(lib, oracle_exact):
     ma = _mesh_arrays(sub)
     ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
     kw = dict(max_iter=1000, epsilon=1e-13)
-    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma, tuning=dict(resort_steps=256))
-    _assert_identical(gpu, ref)
+    for tuning in (dict(resort_steps=256), dict(resort_steps=256, mesh_traversal=4)):
+        gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 123, kw, mesh=ma, tuning=tuning)
+        _assert_identical(gpu, ref)
+
+
+@pytest.mark.parametrize("periodic,init", [(True, "uniform"), (False, "uniform"), (True, "extra")])
+def test_clearance_map_is_invisible_in_open_space(lib, oracle_exact, periodic, init):
+    """A small sphere in a roomy voxel, walkers everywhere / outside: most walkers are farther than a step
+    from every triangle, the launches start with > 40 % of them clear and the kernel skips their traversal
+    (default tuning decides that per launch; 4 forces it, 3 forbids it).  Per-walker results must not move."""
+    from disimpy_amd import simulations, substrates
+
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], periodic, padding=np.zeros(3) + 6e-6, n_sv=np.array([12, 10, 14]),
+                          init_pos=init, quiet=True)
+    n, T, dt = 6000, 300, 2e-4
+    step_l = float(np.sqrt(6 * D * dt))  # 1.5 um
+    g = _random_gradient(2, T)
+    if init == "uniform":
+        pos0 = np.random.RandomState(3).random_sample((n, 3)) * sub.voxel_size
+    else:
+        pos0 = simulations._fill_mesh(n, sub, False, 123)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 9)
+    kw = dict(max_iter=1000, epsilon=1e-13)
+    for tr in (2, 4, 3):
+        gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 9, kw, mesh=ma, tuning=dict(mesh_traversal=tr, resort_steps=64))
+        _assert_identical(gpu, ref)
 
 
 @pytest.mark.parametrize("meas_per_pass", [1, 8])
