@@ -36,6 +36,16 @@ class DsimError(RuntimeError):
     """A call into libdsim_hip.so failed."""
 
 
+class _MissingSymbol:
+    """Stand-in for an entry point a development build (DSIM_LIB=...) does not export."""
+
+    def __init__(self, name):
+        self.name, self.argtypes, self.restype = name, None, None
+
+    def __call__(self, *a):
+        raise DsimError("%s is not exported by %s" % (self.name, LIB_PATH))
+
+
 def load():
     """Load libdsim_hip.so (built by ``__graft_entry__.build()`` / ``make -C disimpy_amd/csrc``)."""
     global _lib
@@ -47,6 +57,14 @@ def load():
             "or `make -C disimpy_amd/csrc` (there is no CPU fallback)" % LIB_PATH
         )
     lib = C.CDLL(LIB_PATH)
+    missing = [name for name in SYMBOLS if not hasattr(lib, name)]
+    if missing:
+        if not os.environ.get("DSIM_LIB"):
+            raise DsimError("%s lacks %s: rebuild it (make -C disimpy_amd/csrc)" % (LIB_PATH, ", ".join(missing)))
+        # DSIM_LIB names a development build (older kernels kept for A/B timing): calling a missing entry
+        # point still fails, loudly, at the call
+        for name in missing:
+            setattr(lib, name, _MissingSymbol(name))
     lib.dsim_last_error.restype = C.c_char_p
     lib.dsim_rng_init.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
     lib.dsim_rng_init_device.argtypes = [_h, C.c_uint64]

@@ -789,6 +789,18 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   double sub_min = 1e300; /* smallest subvoxel edge */
   for (int k = 0; k < 3; k++)
     if (inv_h3[k] > 0) sub_min = std::min(sub_min, 1.0 / inv_h3[k]);
+  /* thresholds of the micro-grid (tuned on the neuron and the packed cylinders); DSIM_MICRO="t1,t2,t3,t4,min_cell"
+   * overrides them for tuning runs - results never depend on them */
+  int micro_t[4] = {4, 16, 64, 1 << 30};
+  double micro_min_cell = 1.5;
+  if (const char *env = getenv("DSIM_MICRO")) {
+    int a, b, c, d;
+    double m;
+    if (sscanf(env, "%d,%d,%d,%d,%lf", &a, &b, &c, &d, &m) == 5 && a >= 0 && b >= a && c >= b && d >= c && m > 0) {
+      micro_t[0] = a, micro_t[1] = b, micro_t[2] = c, micro_t[3] = d;
+      micro_min_cell = m;
+    }
+  }
   std::vector<int2> sv_micro((size_t)n_sub);
   std::vector<int2> cell_range;
   std::vector<float4> mrec;
@@ -806,8 +818,8 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
        * than 8 / 32 / 128), but no cell smaller than 1.5 step lengths: a query box that spans
        * several cells per axis multiplies the cell tasks (packed cylinders with 0.4 um
        * subvoxels: 3.3e9 instead of 7.3e9 spin-steps/s with k = 2) */
-      int lk = n_s <= 4 ? 0 : (n_s <= 16 ? 1 : (n_s <= 64 ? 2 : 3));
-      while (lk > 0 && sub_min / (double)(1 << lk) < 1.5 * step_l) lk--;
+      int lk = n_s <= micro_t[0] ? 0 : (n_s <= micro_t[1] ? 1 : (n_s <= micro_t[2] ? 2 : (n_s <= micro_t[3] ? 3 : 4)));
+      while (lk > 0 && sub_min / (double)(1 << lk) < micro_min_cell * step_l) lk--;
       const int k = 1 << lk;
       const int64_t sx = s / (n_sv[1] * n_sv[2]), sy = (s / n_sv[2]) % n_sv[1], sz = s % n_sv[2];
       const double org[3] = {xs[sx], ys[sy], zs[sz]};
@@ -1742,6 +1754,7 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   DevMesh dm;
   double *px = nullptr, *py = nullptr, *pz = nullptr;
   uint64_t *s0 = nullptr, *s1 = nullptr, *cols = nullptr;
+  int32_t *d_col_start = nullptr, *d_col_x = nullptr;
   int rc = upload_mesh(dm, stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, 0.0);
   auto cleanup = [&]() {
     free_mesh(dm);
@@ -1751,6 +1764,8 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
     if (s0) (void)hipFree(s0);
     if (s1) (void)hipFree(s1);
     if (cols) (void)hipFree(cols);
+    if (d_col_start) (void)hipFree(d_col_start);
+    if (d_col_x) (void)hipFree(d_col_x);
     (void)hipStreamDestroy(stream);
   };
 #define FILL_TRY(expr)                                                                     \
@@ -1780,7 +1795,28 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   const int grid = grid_for(n_points, 256);
   rng_init_kernel<<<grid, 256, 0, stream>>>(sd.s0, sd.s1, 0, n_points, cols, jt.levels, s0, s1);
   FILL_TRY(hipGetLastError());
+  /* per (y, z) column the x indices of the non-empty subvoxels, ascending (see FillParams) */
+  {
+    const int nx = dm.nx, ny = dm.ny, nz = dm.nz;
+    std::vector<int32_t> col_start((size_t)ny * nz + 1, 0), col_x;
+    for (int y = 0; y < ny; y++)
+      for (int z = 0; z < nz; z++) {
+        col_start[(size_t)y * nz + z] = (int32_t)col_x.size();
+        for (int x = 0; x < nx; x++) {
+          const int64_t sv = ((int64_t)x * ny + y) * nz + z;
+          if (subvoxel_indices[sv * 2 + 1] > subvoxel_indices[sv * 2]) col_x.push_back(x);
+        }
+      }
+    col_start[(size_t)ny * nz] = (int32_t)col_x.size();
+    if (col_x.empty()) col_x.push_back(0);
+    FILL_TRY(hipMalloc(&d_col_start, col_start.size() * sizeof(int32_t)));
+    FILL_TRY(hipMalloc(&d_col_x, col_x.size() * sizeof(int32_t)));
+    FILL_TRY(hipMemcpy(d_col_start, col_start.data(), col_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_col_x, col_x.data(), col_x.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   FillParams fp;
+  fp.col_start = d_col_start;
+  fp.col_x = d_col_x;
   fp.n_points = n_points;
   fp.px = px;
   fp.py = py;

@@ -195,38 +195,40 @@ DSD V3 load_v3(const double *p) {
  * meet this box cannot return 0 < d <= step_l from the Moller-Trumbore test, so
  * skipping it changes neither the decision `min_d > step_l` nor the closest
  * triangle when there is a hit (simulations.py:981-986): results stay
- * bit-identical to testing every candidate.  The margin (1e-6 step_l plus 2.4e-7
- * of the coordinate, i.e. 4 float32 ulps) dwarfs every fp64 rounding error of
- * the test itself (~1e-16 relative). */
+ * bit-identical to testing every candidate.
+ *
+ * The box is DERIVED from seven numbers - the segment's midpoint m and half vector h rounded to
+ * float32 and the margin tau = 1e-6 step_l + 2e-6 of the largest coordinate magnitude (16 float32
+ * ulps of it): the bounds are m -+ (|h| + tau).  That margin covers the half-ulp roundings of m and h
+ * many times over and dwarfs every fp64 rounding error of the test itself (~1e-16 relative); it is
+ * also the plane-side margin (the float32 evaluation of n.m - c carries an absolute error below
+ * ~8 ulp of the largest coordinate).  Only the seven numbers travel between lanes. */
 struct CullBox {
   float lox, loy, loz, hix, hiy, hiz;
-  float ax, ay, az, ex, ey, ez; /* segment end points in float32 */
-  float tau;                    /* plane-side margin */
+  float mx, my, mz, hx, hy, hz; /* midpoint and half vector of the segment in float32 */
+  float tau;                    /* box and plane-side margin */
 };
 
+DSD void box_from_segment(CullBox &c) {
+  const float ex = __builtin_fabsf(c.hx) + c.tau, ey = __builtin_fabsf(c.hy) + c.tau, ez = __builtin_fabsf(c.hz) + c.tau;
+  c.lox = c.mx - ex, c.hix = c.mx + ex;
+  c.loy = c.my - ey, c.hiy = c.my + ey;
+  c.loz = c.mz - ez, c.hiz = c.mz + ez;
+}
+
 DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
-  V3 e = {__builtin_fma(step.x, step_l, a.x), __builtin_fma(step.y, step_l, a.y), __builtin_fma(step.z, step_l, a.z)};
-  const double ms = 1e-6 * step_l, mr = 2.4e-7;
-  double mx = ms + mr * __builtin_fmax(__builtin_fabs(a.x), __builtin_fabs(e.x));
-  double my = ms + mr * __builtin_fmax(__builtin_fabs(a.y), __builtin_fabs(e.y));
-  double mz = ms + mr * __builtin_fmax(__builtin_fabs(a.z), __builtin_fabs(e.z));
+  const double hl = 0.5 * step_l;
   CullBox c;
-  c.lox = (float)(__builtin_fmin(a.x, e.x) - mx);
-  c.loy = (float)(__builtin_fmin(a.y, e.y) - my);
-  c.loz = (float)(__builtin_fmin(a.z, e.z) - mz);
-  c.hix = (float)(__builtin_fmax(a.x, e.x) + mx);
-  c.hiy = (float)(__builtin_fmax(a.y, e.y) + my);
-  c.hiz = (float)(__builtin_fmax(a.z, e.z) + mz);
-  c.ax = (float)a.x;
-  c.ay = (float)a.y;
-  c.az = (float)a.z;
-  c.ex = (float)e.x;
-  c.ey = (float)e.y;
-  c.ez = (float)e.z;
-  /* float32 evaluation of n.x - c carries an absolute error below ~8 ulp of the largest
-   * coordinate; tau = 16 ulp of it plus the step margin */
+  c.mx = (float)__builtin_fma(step.x, hl, a.x);
+  c.my = (float)__builtin_fma(step.y, hl, a.y);
+  c.mz = (float)__builtin_fma(step.z, hl, a.z);
+  c.hx = (float)(step.x * hl);
+  c.hy = (float)(step.y * hl);
+  c.hz = (float)(step.z * hl);
+  /* magnitude of the largest coordinate of either end point: |a| + step_l bounds both */
   double big = __builtin_fmax(__builtin_fmax(__builtin_fabs(a.x), __builtin_fabs(a.y)), __builtin_fabs(a.z)) + step_l;
-  c.tau = (float)(ms + 2e-6 * big);
+  c.tau = (float)(1e-6 * step_l + 2e-6 * big);
+  box_from_segment(c);
   return c;
 }
 
@@ -260,9 +262,9 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
         continue;
       /* (2) both end points strictly on one side of the triangle's plane (margin tau): the
        * ray cannot meet the plane at 0 < d <= step_l.  Degenerate triangles have n = 0. */
-      const float s0 = __builtin_fmaf(q2[u].x, cb.az, __builtin_fmaf(q1[u].z, cb.ax, q1[u].w * cb.ay)) - q2[u].y;
-      const float s1 = __builtin_fmaf(q2[u].x, cb.ez, __builtin_fmaf(q1[u].z, cb.ex, q1[u].w * cb.ey)) - q2[u].y;
-      if ((s0 > cb.tau && s1 > cb.tau) || (s0 < -cb.tau && s1 < -cb.tau)) continue;
+      const float sm = __builtin_fmaf(q2[u].x, cb.mz, __builtin_fmaf(q1[u].z, cb.mx, q1[u].w * cb.my)) - q2[u].y;
+      const float sh = __builtin_fmaf(q2[u].x, cb.hz, __builtin_fmaf(q1[u].z, cb.hx, q1[u].w * cb.hy));
+      if (__builtin_fabsf(sm) - __builtin_fabsf(sh) > cb.tau) continue;
       STAT_LANE(6);
       STAT_WAVE(6);
       int ti = __float_as_int(q2[u].z), pos = __float_as_int(q2[u].w);
@@ -840,6 +842,11 @@ __global__ void scatter_rows_kernel(const int32_t *orig, int64_t n, const double
 /* ---- _cuda_fill_mesh (simulations.py:421-502) ------------------------------------ */
 
 struct FillParams {
+  /* per (y, z) column of the index: the x coordinates of its NON-EMPTY subvoxels in ascending order,
+   * col_x[col_start[c] .. col_start[c + 1]).  A +x ray only ever walks along one column, and on a sparse mesh
+   * (the neuron: 1.8 % of the subvoxels hold triangles) almost all of the ~nx/2 subvoxels it crosses are empty:
+   * skipping them changes neither the triangles met nor their order. */
+  const int32_t *col_start, *col_x;
   int64_t n_points;
   double *px, *py, *pz; /* +inf where no point has been accepted yet */
   uint64_t *s0, *s1;
@@ -877,9 +884,16 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
   int n_hits = 0;
   int32_t hits[FILL_MAX_HITS]; /* private (scratch) memory, like the reference's cuda.local.array(1000) */
   const float fy = (float)pt.y, fz = (float)pt.z;
-  for (int x = llx; x < ulx; x++)
-    for (int y = lly; y < uly; y++)
-      for (int z = llz; z < ulz; z++) {
+  /* the reference's loop order is x, y, z (:461-463); y and z ranges of a +x ray hold one subvoxel each unless
+   * the point sits exactly on a boundary (then they are empty or the loop below still visits x-major per column -
+   * the set of triangles met is the same and only their count matters) */
+  for (int y = lly; y < uly; y++)
+    for (int z = llz; z < ulz; z++) {
+      const int col = y * ms.nz + z;
+      for (int e = p.col_start[col]; e < p.col_start[col + 1]; e++) {
+        const int x = p.col_x[e];
+        if (x < llx) continue;
+        if (x >= ulx) break;
         int sv = (x * ms.ny + y) * ms.nz + z;
         int2 range = ms.sv_range[sv];
         for (int i = range.x; i < range.y; i++) {
@@ -902,6 +916,7 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
           }
         }
       }
+    }
   bool inside = (n_hits & 1) == 1;
   if (p.intra ? inside : !inside) {
     p.px[tid] = pt.x;

@@ -25,8 +25,9 @@
  * Stages 1c-3 run in rounds (cells are expanded while the item queue has room,
  * items are drained in full trips of 64, the survivor pool is flushed in full
  * trips of 64), so the queue sizes bound the LDS footprint, not the work per
- * pass.  The owners' boxes and rays stay in the owners' registers and are read
- * with ds_bpermute; the kernel then fits 128 VGPRs and 8 KB of LDS per
+ * pass.  The owners' segments (midpoint, half vector and margin: 7 floats, from which the
+ * working lane rebuilds the cull box) and rays stay in the owners' registers and
+ * are read with ds_bpermute; the kernel then fits 128 VGPRs and 8 KB of LDS per
  * wavefront, i.e. 4 wavefronts per SIMD.
  *
  * Which triangles are tested, in fp64, against which ray is unchanged, and the
@@ -99,28 +100,19 @@ DSD void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* cull box moved into the frame of a periodic image (shift subtracted), inflated by the
- * float32 rounding of the subtraction; shift = 0 returns the box unchanged */
+/* segment moved into the frame of a periodic image (shift subtracted from its midpoint), margin grown by
+ * the float32 rounding of the subtraction; shift = 0 returns the box unchanged */
 DSD CullBox shift_cull_box(const CullBox &c, double shx, double shy, double shz) {
   if (shx == 0 && shy == 0 && shz == 0) return c;
   const float sx = (float)shx, sy = (float)shy, sz = (float)shz;
-  const float mx = 5e-7f * (__builtin_fabsf(sx) + __builtin_fmaxf(__builtin_fabsf(c.lox), __builtin_fabsf(c.hix)));
-  const float my = 5e-7f * (__builtin_fabsf(sy) + __builtin_fmaxf(__builtin_fabsf(c.loy), __builtin_fabsf(c.hiy)));
-  const float mz = 5e-7f * (__builtin_fabsf(sz) + __builtin_fmaxf(__builtin_fabsf(c.loz), __builtin_fabsf(c.hiz)));
-  CullBox o;
-  o.lox = c.lox - sx - mx;
-  o.loy = c.loy - sy - my;
-  o.loz = c.loz - sz - mz;
-  o.hix = c.hix - sx + mx;
-  o.hiy = c.hiy - sy + my;
-  o.hiz = c.hiz - sz + mz;
-  o.ax = c.ax - sx;
-  o.ay = c.ay - sy;
-  o.az = c.az - sz;
-  o.ex = c.ex - sx;
-  o.ey = c.ey - sy;
-  o.ez = c.ez - sz;
-  o.tau = c.tau + 4.0f * (mx + my + mz);
+  CullBox o = c;
+  o.mx = c.mx - sx;
+  o.my = c.my - sy;
+  o.mz = c.mz - sz;
+  /* rounding of the shifts and of the three subtractions: a few float32 ulps of the larger operand each */
+  o.tau = c.tau + 2e-6f * (__builtin_fabsf(sx) + __builtin_fabsf(sy) + __builtin_fabsf(sz) + __builtin_fabsf(c.mx) +
+                           __builtin_fabsf(c.my) + __builtin_fabsf(c.mz));
+  box_from_segment(o);
   return o;
 }
 
@@ -143,24 +135,18 @@ DSD void offer_hit(BestHit &b, double d, int visit, int pos, int tri) {
   }
 }
 
-DSD bool cull_record(const float4 &q0, const float4 &q1, const float4 &q2, const CullBox &cb) {
-  if (q0.x > cb.hix || q0.w < cb.lox || q0.y > cb.hiy || q1.x < cb.loy || q0.z > cb.hiz || q1.y < cb.loz) return true;
-  const float s0 = __builtin_fmaf(q2.x, cb.az, __builtin_fmaf(q1.z, cb.ax, q1.w * cb.ay)) - q2.y;
-  const float s1 = __builtin_fmaf(q2.x, cb.ez, __builtin_fmaf(q1.z, cb.ex, q1.w * cb.ey)) - q2.y;
-  return (s0 > cb.tau && s1 > cb.tau) || (s0 < -cb.tau && s1 < -cb.tau);
-}
-
-/* the same decision as cull_record() as ONE number, without branches or mask arithmetic: > 0 when the record
- * can be skipped.  max over (a) the six box gaps - a positive gap on any axis separates the triangle's box from
- * the segment's - and (b) how far beyond the margin tau BOTH end points lie on one side of the triangle's
- * plane.  Every rounding / flush-to-zero / NaN case falls on the "keep" side or concerns a walker whose fp64
- * test cannot hit anyway. */
+/* > 0 when the record can be skipped - ONE number, no branches or mask arithmetic: the max over (a) the six box
+ * gaps (a positive gap on any axis separates the triangle's box from the segment's) and (b) how far beyond the
+ * margin tau the whole segment lies on one side of the triangle's plane: with the midpoint m and the half vector
+ * h of the segment, the end points evaluate to (n.m - c) -+ n.h, so both are beyond tau on the same side iff
+ * |n.m - c| - |n.h| > tau.  Every rounding / flush-to-zero / NaN case falls on the "keep" side or concerns a
+ * walker whose fp64 test cannot hit anyway. */
 DSD float cull_margin(const float4 &q0, const float4 &q1, const float4 &q2, const CullBox &cb) {
   const float g1 = __builtin_fmaxf(__builtin_fmaxf(q0.x - cb.hix, q0.y - cb.hiy), q0.z - cb.hiz);
   const float g2 = __builtin_fmaxf(__builtin_fmaxf(cb.lox - q0.w, cb.loy - q1.x), cb.loz - q1.y);
-  const float s0 = __builtin_fmaf(q2.x, cb.az, __builtin_fmaf(q1.z, cb.ax, q1.w * cb.ay)) - q2.y;
-  const float s1 = __builtin_fmaf(q2.x, cb.ez, __builtin_fmaf(q1.z, cb.ex, q1.w * cb.ey)) - q2.y;
-  const float side = __builtin_fmaxf(__builtin_fminf(s0, s1) - cb.tau, -__builtin_fmaxf(s0, s1) - cb.tau);
+  const float sm = __builtin_fmaf(q2.x, cb.mz, __builtin_fmaf(q1.z, cb.mx, q1.w * cb.my)) - q2.y;
+  const float sh = __builtin_fmaf(q2.x, cb.hz, __builtin_fmaf(q1.z, cb.hx, q1.w * cb.hy));
+  const float side = (__builtin_fabsf(sm) - __builtin_fabsf(sh)) - cb.tau;
   return __builtin_fmaxf(__builtin_fmaxf(g1, g2), side);
 }
 
@@ -426,8 +412,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         STAT_WAVE(1);
         mg = ms.sv_micro[sv];
       }
-      CullBox cb = {__shfl(cb0.lox, owner, 64), __shfl(cb0.loy, owner, 64), __shfl(cb0.loz, owner, 64), __shfl(cb0.hix, owner, 64),
-                    __shfl(cb0.hiy, owner, 64), __shfl(cb0.hiz, owner, 64), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      /* the owner's segment (7 floats through ds_bpermute); the box is rebuilt from it on this side */
+      CullBox cb = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, __shfl(cb0.mx, owner, 64), __shfl(cb0.my, owner, 64), __shfl(cb0.mz, owner, 64),
+                    __shfl(cb0.hx, owner, 64), __shfl(cb0.hy, owner, 64), __shfl(cb0.hz, owner, 64), __shfl(cb0.tau, owner, 64)};
+      box_from_segment(cb);
       const bool has = mg.x != 0 && !ABLATE(1); /* not an empty subvoxel (or no task for this lane) */
       int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
       if (mg.x > 0 && !ABLATE(1)) {
@@ -436,10 +424,17 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
         }
         k = 1 << mg.y;
-        const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
-        a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
-        b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
-        c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+        /* The cells the box reaches, in float32 and WIDENED: any superset of the exact cells of micro_cell() is
+         * valid (an extra cell only costs its records a look).  The float32 evaluation of (c - x0) * scale is off
+         * by < 0.5 ulp of the subvoxel origin times scale + a few ulps of the result, i.e. < 3e-7 k n_sv + 1e-6 k
+         * cells; the ranges are widened by dl >= 1e-3 + 5e-7 k n_sv cells on both sides. */
+        const float kf = (float)k;
+        const float dl = __builtin_fmaf(5e-7f * kf, (float)max(ms.nx, max(ms.ny, ms.nz)), 1e-3f);
+        const float sx = kf * (float)ms.inv_hx, sy = kf * (float)ms.inv_hy, sz = kf * (float)ms.inv_hz;
+        const float ox = (float)xs[x], oy = (float)ys[y], oz = (float)zs[z];
+        a0 = min(max((int)((cb.lox - ox) * sx - dl), 0), k - 1), a1 = min(max((int)((cb.hix - ox) * sx + dl), 0), k - 1);
+        b0 = min(max((int)((cb.loy - oy) * sy - dl), 0), k - 1), b1 = min(max((int)((cb.hiy - oy) * sy + dl), 0), k - 1);
+        c0 = min(max((int)((cb.loz - oz) * sz - dl), 0), k - 1), c1 = min(max((int)((cb.hiz - oz) * sz + dl), 0), k - 1);
       }
       /* queue slots from a prefix sum over the lanes (DPP; no LDS atomic) */
       const int ncell = has ? (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1) : 0;
@@ -534,11 +529,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         if (valid) it = items[idx];
         const int owner = (int)(it.y & 63u);
         CullBox cb;
-        cb.lox = __shfl(cb0.lox, owner, 64), cb.loy = __shfl(cb0.loy, owner, 64), cb.loz = __shfl(cb0.loz, owner, 64);
-        cb.hix = __shfl(cb0.hix, owner, 64), cb.hiy = __shfl(cb0.hiy, owner, 64), cb.hiz = __shfl(cb0.hiz, owner, 64);
-        cb.ax = __shfl(cb0.ax, owner, 64), cb.ay = __shfl(cb0.ay, owner, 64), cb.az = __shfl(cb0.az, owner, 64);
-        cb.ex = __shfl(cb0.ex, owner, 64), cb.ey = __shfl(cb0.ey, owner, 64), cb.ez = __shfl(cb0.ez, owner, 64);
+        cb.mx = __shfl(cb0.mx, owner, 64), cb.my = __shfl(cb0.my, owner, 64), cb.mz = __shfl(cb0.mz, owner, 64);
+        cb.hx = __shfl(cb0.hx, owner, 64), cb.hy = __shfl(cb0.hy, owner, 64), cb.hz = __shfl(cb0.hz, owner, 64);
         cb.tau = __shfl(cb0.tau, owner, 64);
+        box_from_segment(cb);
         if (valid) {
         STAT_LANE(4);
         STAT_WAVE(4);

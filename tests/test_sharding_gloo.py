@@ -87,3 +87,48 @@ def test_two_rank_gloo_reduce_matches_single_process():
         np.testing.assert_allclose(ts, s, rtol=0, atol=1e-12 * n)
         assert nexc == 0
     np.testing.assert_array_equal(got[0][1], got[1][1])  # every rank holds the same total
+
+
+def _worker_empty(rank, world, port, n, q):
+    """More ranks than walkers: the rank with an empty range goes through simulation_sharded() itself (it must
+    not touch the GPU and must still take part in the collective), the others stand in with the oracle."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disimpy_amd import gradients, sharding, substrates
+    from oracle.oracle import FREE, Oracle
+
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 30, np.array([1e9, 5e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    a, b = sharding.shard_range(n, rank, world)
+    if b == a:
+        tc = sharding.simulation_sharded(n, 2e-9, gradient, dt, substrates.free(), seed=123, dist=dist)
+    else:
+        step_l = float(np.sqrt(6 * 2e-9 * dt))
+        o = Oracle(exact=False)
+        st = o.rng_states(b, 123)[a:].copy()
+        pos = np.zeros((b - a, 3))
+        ph, exc, _ = o.run(o.geom(FREE), gradient, dt, step_l, pos, st)
+        c, s = o.signal(ph, exc)
+        tc, _, _ = sharding.reduce_signal(c, s, 0, dist)
+    q.put((rank, (a, b), tc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_with_an_empty_shard_still_joins_the_reduction():
+    n, world = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_empty, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [(0, 1), (1, 2), (2, 2)]
+    for g in got[1:]:
+        np.testing.assert_array_equal(g[2], got[0][2])
+    assert np.all(np.abs(got[0][2]) <= n)

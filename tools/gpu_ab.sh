@@ -1,15 +1,19 @@
-# A/B of the mesh kernel variants on the GPU box: bench lines for the given --mesh-traversal values
-# usage: bash tools/gpu_ab.sh <tag> "<walkers list>" "<workloads>" "<traversals>"
-TAG=$1; WALKERS=${2:-"1000000 10000000"}; WLS=${3:-"c5b"}; TRS=${4:-"3 2"}
+# Same-box A/B of kernel variants: every library in LIBS runs the same bench line (MI355X boxes differ by
+# several per cent between calls, so only numbers from ONE call compare).  Initial positions are computed
+# once per (workload, walkers) and cached in /tmp.
+# usage: bash tools/gpu_ab.sh <tag> <workload> <walkers> "<lib1> <lib2> ..." ["extra bench args"]
+TAG=$1; WL=$2; N=$3; LIBS=$4; EXTRA=$5
 mkdir -p gpurun_out/r02
-for wl in $WLS; do for n in $WALKERS; do for tr in $TRS; do
-  python bench.py --workload $wl --walkers $n --steps 2 --warmup 1 --mesh-traversal $tr --no-cpu-baseline --no-secondary --no-signal-check > gpurun_out/r02/ab_${TAG}_${wl}_${n}_tr${tr}.json 2> gpurun_out/r02/ab_${TAG}_${wl}_${n}_tr${tr}.err
+for rep in 1 2; do for lib in $LIBS; do
+  name=$(basename $lib .so)
+  out=gpurun_out/r02/ab_${TAG}_${name}_${rep}
+  DSIM_BENCH_POSITIONS_CACHE=/tmp/pos_${WL}_${N}.npy DSIM_LIB=$PWD/disimpy_amd/csrc/$lib python bench.py --workload $WL --walkers $N --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check $EXTRA > $out.json 2> $out.err
   python - <<PY
 import json
 try:
-    d=json.loads(open("gpurun_out/r02/ab_${TAG}_${wl}_${n}_tr${tr}.json").read().strip().splitlines()[-1])
-    print("${TAG} ${wl} n=${n} traversal=${tr}: value %.4g  walk-kernel %.4g  S/N %.6f" % (d["value"], d["walk_kernel_spin_steps_per_s"], d["signal_check"]["last_pass_mean_S_over_N"]))
+    d=json.loads(open("$out.json").read().strip().splitlines()[-1])
+    print("${TAG} ${WL} n=${N} ${name} rep${rep}: value %.4g  walk-kernel %.4g  S/N %.9f" % (d["value"], d["walk_kernel_spin_steps_per_s"], d["signal_check"]["last_pass_mean_S_over_N"]))
 except Exception as e:
-    print("${TAG} ${wl} ${n} ${tr} FAILED", e); print(open("gpurun_out/r02/ab_${TAG}_${wl}_${n}_tr${tr}.err").read()[-1500:])
+    print("${TAG} ${name} FAILED", e); print(open("$out.err").read()[-1500:])
 PY
-done; done; done
+done; done
