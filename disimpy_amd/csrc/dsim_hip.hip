@@ -744,16 +744,30 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   if (n_sub > INT32_MAX) return fail(DSIM_ERR_INVALID, "mesh: too many subvoxels");
   free_mesh(dm);
   /* pre-gathered triangle records {A, B - A, C - A} (simulations.py:259-262 does these subtractions per candidate) */
-  std::vector<double> rec((size_t)n_faces * 9);
+  std::vector<double> rec((size_t)n_faces * DS_TRI_STRIDE);
   for (int64_t f = 0; f < n_faces; f++) {
     int64_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
     if (ia < 0 || ib < 0 || ic < 0 || ia >= n_vertices || ib >= n_vertices || ic >= n_vertices)
       return fail(DSIM_ERR_INVALID, "mesh: face %lld references a vertex out of range", (long long)f);
     for (int k = 0; k < 3; k++) {
       double a = vertices[ia * 3 + k];
-      rec[f * 9 + k] = a;
-      rec[f * 9 + 3 + k] = vertices[ib * 3 + k] - a;
-      rec[f * 9 + 6 + k] = vertices[ic * 3 + k] - a;
+      rec[f * DS_TRI_STRIDE + k] = a;
+      rec[f * DS_TRI_STRIDE + 3 + k] = vertices[ib * 3 + k] - a;
+      rec[f * DS_TRI_STRIDE + 6 + k] = vertices[ic * 3 + k] - a;
+    }
+    /* unit normal = normalize((A-B) x (A-C)) (simulations.py:77-97) with the device's own operations: cross3 and
+     * dot3 in the fma convention of dsim_device.h, correctly rounded sqrt (= ds_sqrt_dev, tested over the whole
+     * range), ds_div3 (same source on host and device).  A degenerate triangle gets the same NaNs as on the device. */
+    {
+      const double *e1 = &rec[f * DS_TRI_STRIDE + 3], *e2 = &rec[f * DS_TRI_STRIDE + 6];
+      double nx = std::fma(e1[1], e2[2], -(e1[2] * e2[1]));
+      double ny = std::fma(e1[2], e2[0], -(e1[0] * e2[2]));
+      double nz = std::fma(e1[0], e2[1], -(e1[1] * e2[0]));
+      const double len = std::sqrt(std::fma(nz, nz, std::fma(nx, nx, ny * ny)));
+      ds_div3(&nx, &ny, &nz, len);
+      rec[f * DS_TRI_STRIDE + 9] = nx;
+      rec[f * DS_TRI_STRIDE + 10] = ny;
+      rec[f * DS_TRI_STRIDE + 11] = nz;
     }
   }
   std::vector<int2> ranges((size_t)n_sub);
@@ -791,7 +805,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (inv_h3[k] > 0) sub_min = std::min(sub_min, 1.0 / inv_h3[k]);
   /* thresholds of the micro-grid (tuned on the neuron and the packed cylinders); DSIM_MICRO="t1,t2,t3,t4,min_cell"
    * overrides them for tuning runs - results never depend on them */
-  int micro_t[4] = {4, 16, 64, 1 << 30};
+  int micro_t[4] = {2, 4, 16, 1 << 30};
   double micro_min_cell = 1.5;
   if (const char *env = getenv("DSIM_MICRO")) {
     int a, b, c, d;
@@ -814,10 +828,12 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
         sv_micro[s] = make_int2(0, 0);
         continue;
       }
-      /* k^3 micro-cells for more than 4 / 16 / 64 references (measured on the neuron: 4.5 % faster
-       * than 8 / 32 / 128), but no cell smaller than 1.5 step lengths: a query box that spans
+      /* k^3 micro-cells (k = 2 / 4 / 8) for more than 2 / 4 / 16 references - round 2, with the cheaper
+       * branch-free record test: 5 % faster on the refined neuron than round 1's 4 / 16 / 64, itself 4.5 %
+       * faster than 8 / 32 / 128; {1,4,12}, {1,3,12}, {2,6,24} and k = 16 for the densest subvoxels are all
+       * within 0.5 % of it - but no cell smaller than 1.5 step lengths: a query box that spans
        * several cells per axis multiplies the cell tasks (packed cylinders with 0.4 um
-       * subvoxels: 3.3e9 instead of 7.3e9 spin-steps/s with k = 2) */
+       * subvoxels: 3.3e9 instead of 7.3e9 spin-steps/s with k = 2; 2.0 step lengths cost the neuron 5 %) */
       int lk = n_s <= micro_t[0] ? 0 : (n_s <= micro_t[1] ? 1 : (n_s <= micro_t[2] ? 2 : (n_s <= micro_t[3] ? 3 : 4)));
       while (lk > 0 && sub_min / (double)(1 << lk) < micro_min_cell * step_l) lk--;
       const int k = 1 << lk;
@@ -862,7 +878,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
           memcpy(&pos_bits, &i, sizeof(float));
           /* supporting plane n.x = c in float32 (unit normal; c from the ROUNDED normal so that the
            * float32 plane is self-consistent); a degenerate triangle gets n = 0, c = 0 and is never culled */
-          const double *r = &rec[(size_t)ti * 9];
+          const double *r = &rec[(size_t)ti * DS_TRI_STRIDE];
           double nx = r[4] * r[8] - r[5] * r[7], ny = r[5] * r[6] - r[3] * r[8], nz = r[3] * r[7] - r[4] * r[6];
           double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
           float fx = 0.f, fy = 0.f, fz = 0.f, fc = 0.f;

@@ -63,8 +63,13 @@ __device__ int dsim_ablate = 0;
 
 enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };
 
+#define DS_TRI_STRIDE 12 /* doubles per triangle record */
+
 struct MeshDev {
-  const double *tri;       /* [n_faces][9]  {A, E1, E2}                  */
+  const double *tri;       /* [n_faces][12] {A, E1 = B - A, E2 = C - A, unit normal}: the normal is
+                              normalize(E1 x E2) evaluated once on the host with the kernel's own operations
+                              (same fma convention, IEEE sqrt, ds_div3) instead of after every hit
+                              (simulations.py:989-990 recomputes it per reflection) */
   const int2 *sv_range;    /* [prod n_sv]   [start, end) into tri_idx    */
   const int32_t *tri_idx;  /* [n_refs]                                   */
   const int2 *sv_micro;    /* [prod n_sv]   {0,0} empty | {-(first record + 1), count}: one cell, inline |
@@ -217,17 +222,21 @@ DSD void box_from_segment(CullBox &c) {
 }
 
 DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
-  const double hl = 0.5 * step_l;
+  /* float32 arithmetic from the start: start point and direction rounded once (half an ulp each), the midpoint one
+   * more rounding - about one ulp of the largest coordinate in all, against a margin of sixteen */
+  const float ax = (float)a.x, ay = (float)a.y, az = (float)a.z;
+  const float sx = (float)step.x, sy = (float)step.y, sz = (float)step.z;
+  const float sl = (float)step_l, hl = 0.5f * sl;
   CullBox c;
-  c.mx = (float)__builtin_fma(step.x, hl, a.x);
-  c.my = (float)__builtin_fma(step.y, hl, a.y);
-  c.mz = (float)__builtin_fma(step.z, hl, a.z);
-  c.hx = (float)(step.x * hl);
-  c.hy = (float)(step.y * hl);
-  c.hz = (float)(step.z * hl);
-  /* magnitude of the largest coordinate of either end point: |a| + step_l bounds both */
-  double big = __builtin_fmax(__builtin_fmax(__builtin_fabs(a.x), __builtin_fabs(a.y)), __builtin_fabs(a.z)) + step_l;
-  c.tau = (float)(1e-6 * step_l + 2e-6 * big);
+  c.hx = sx * hl;
+  c.hy = sy * hl;
+  c.hz = sz * hl;
+  c.mx = ax + c.hx;
+  c.my = ay + c.hy;
+  c.mz = az + c.hz;
+  /* magnitude of the largest coordinate of either end point: |a| + step_l bounds both (|step| = 1) */
+  const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az)) + sl;
+  c.tau = __builtin_fmaf(2.0001e-6f, big, 1.0001e-6f * sl);
   box_from_segment(c);
   return c;
 }
@@ -268,7 +277,7 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
       STAT_LANE(6);
       STAT_WAVE(6);
       int ti = __float_as_int(q2[u].z), pos = __float_as_int(q2[u].w);
-      const double *rec = ms.tri + (int64_t)ti * 9;
+      const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
       double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
       if (d > 0 && (d < min_d || (d == min_d && pos < pass_pos))) {
         closest = ti;
@@ -364,9 +373,8 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
       STAT_LANE(7);
       STAT_WAVE(7);
       bool reflect = p.perm_prob < rng_uniform_f64(rng);
-      const double *rec = ms.tri + (int64_t)closest * 9;
-      V3 n = cross3(load_v3(rec + 3), load_v3(rec + 6)); /* (A-B)x(A-C) == E1 x E2 bit for bit */
-      normalize3(n);
+      const double *rec = ms.tri + (int64_t)closest * DS_TRI_STRIDE;
+      V3 n = load_v3(rec + 9); /* normalize((A-B) x (A-C)), precomputed: (A-B)x(A-C) == E1 x E2 bit for bit */
       if (reflect)
         reflection(r0, step, min_d, n, p.eps);
       else
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
            * others cannot change the hit count (the fp64 test would return NaN for them) */
           const float4 yz = ms.tri_yz[ti];
           if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
-          const double *rec = ms.tri + (int64_t)ti * 9;
+          const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
           double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
           if (d > 0) {
             bool already = false;

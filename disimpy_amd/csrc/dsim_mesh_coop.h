@@ -54,7 +54,7 @@
 struct CoopWave {
   unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)      0.5 KB */
   unsigned long long best_key[64];      /* (visit << 32) | list position of the winner                  0.5 KB */
-  double best_n[64][3];                 /* E1 x E2 of the winner's triangle (un-normalised normal)      1.5 KB */
+  double best_n[64][3];                 /* unit normal of the winner's triangle                          1.5 KB */
   uint2 cellq[COOP_CELLQ_CAP];          /* cell tasks {owner|visit|shifts, index into cell_range  or
                                            0x80000000 | subvoxel (range stored inline)} (1b -> 1c)      2.0 KB */
   /* the next four arrays (3.5 KB) also hold, between stages 1a and 1b, the subvoxel tasks
@@ -144,7 +144,7 @@ DSD void offer_hit(BestHit &b, double d, int visit, int pos, int tri) {
 DSD float cull_margin(const float4 &q0, const float4 &q1, const float4 &q2, const CullBox &cb) {
   const float g1 = __builtin_fmaxf(__builtin_fmaxf(q0.x - cb.hix, q0.y - cb.hiy), q0.z - cb.hiz);
   const float g2 = __builtin_fmaxf(__builtin_fmaxf(cb.lox - q0.w, cb.loy - q1.x), cb.loz - q1.y);
-  const float sm = __builtin_fmaf(q2.x, cb.mz, __builtin_fmaf(q1.z, cb.mx, q1.w * cb.my)) - q2.y;
+  const float sm = __builtin_fmaf(q2.x, cb.mz, __builtin_fmaf(q1.z, cb.mx, __builtin_fmaf(q1.w, cb.my, -q2.y)));
   const float sh = __builtin_fmaf(q2.x, cb.hz, __builtin_fmaf(q1.z, cb.hx, q1.w * cb.hy));
   const float side = (__builtin_fabsf(sm) - __builtin_fabsf(sh)) - cb.tau;
   return __builtin_fmaxf(__builtin_fmaxf(g1, g2), side);
@@ -189,7 +189,7 @@ DSD void iteration_serial(const MeshDev &ms, const SubvoxelWalk &w, const V3 &r0
         const V3 tr0 = {r0.x - (double)snx * Lx, r0.y - (double)sny * Ly, r0.z - (double)snz * Lz};
         for (int i = rg.x; i < rg.y; i++) {
           const int ti = ms.tri_idx[i];
-          const double *rec = ms.tri + (int64_t)ti * 9;
+          const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
           const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
           offer_hit(best, d, v, i, ti);
         }
@@ -249,16 +249,43 @@ DSD bool push_subvoxels(const MeshDev &ms, const SubvoxelWalk &w, int nsub, Coop
   return true;
 }
 
+/* Both periodic subvoxel limits of one axis in float32, for the common case that decides itself: the boundaries
+ * are np.linspace(x0, x0 + L, n + 1), image k of boundary i sits at (k n + i) h, so for a coordinate that is NOT
+ * within 1e-4 subvoxel widths of any boundary the reference's scans (simulations.py:616-679) end at
+ * ll = floor(t_min), ul = floor(t_max) + 1 with t = (x - x0) / h - whatever arithmetic produced t, as long as its
+ * error stays below that distance.  t is the fp64 product rounded once to float32 (relative error 6e-8).  The
+ * caller accepts when `edge` < 0.4999 on every axis (both fractional parts farther than 1e-4 from 0 and 1) and
+ * the sum of all six |t| is below 1500 (so every |t| < 1500 and its error < 9e-5); otherwise - too close to a
+ * boundary, too far out, or not a number - it takes the exact fp64 path. */
+DSD void subvoxel_limits_f32(double x0, double inv_h, double x1, double x2, int &ll, int &ul, float &edge, float &reach) {
+  const float t1 = (float)((x1 - x0) * inv_h), t2 = (float)((x2 - x0) * inv_h);
+  const float tmin = __builtin_fminf(t1, t2), tmax = __builtin_fmaxf(t1, t2);
+  const float fmin = __builtin_floorf(tmin), fmax = __builtin_floorf(tmax);
+  ll = (int)fmin;
+  ul = (int)fmax + 1;
+  /* distance of the fractional parts from 1/2: below 0.4999 = farther than 1e-4 from both neighbouring boundaries */
+  edge = __builtin_fmaxf(__builtin_fabsf((tmin - fmin) - 0.5f), __builtin_fabsf((tmax - fmax) - 0.5f));
+  reach = __builtin_fabsf(t1) + __builtin_fabsf(t2); /* an addition: NaN survives it (min / max would drop it) */
+}
+
 /* subvoxel ranges (simulations.py:929-934) and cull box of the remaining segment */
 DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double step_l, const double *xs, const double *ys,
                        const double *zs, SubvoxelWalk &sw, CullBox &cb0) {
   const double ex = __builtin_fma(step.x, step_l, r0.x);
   const double ey = __builtin_fma(step.y, step_l, r0.y);
   const double ez = __builtin_fma(step.z, step_l, r0.z);
+  cb0 = make_cull_box(r0, step, step_l);
+  {
+    float e0, e1, e2, q0, q1, q2;
+    subvoxel_limits_f32(ms.x0, ms.inv_hx, r0.x, ex, sw.llx, sw.ulx, e0, q0);
+    subvoxel_limits_f32(ms.y0, ms.inv_hy, r0.y, ey, sw.lly, sw.uly, e1, q1);
+    subvoxel_limits_f32(ms.z0, ms.inv_hz, r0.z, ez, sw.llz, sw.ulz, e2, q2);
+    /* decided on all three axes: 99.9 % of the segments (NaN fails both comparisons) */
+    if (__builtin_fmaxf(__builtin_fmaxf(e0, e1), e2) < 0.4999f && (q0 + q1) + q2 < 1500.0f) return;
+  }
   const bool fx = subvoxel_limits_fast(xs, ms.nx, ms.x0, ms.x1, ms.inv_hx, ms.inv_lx, r0.x, ex, sw.llx, sw.ulx);
   const bool fy = subvoxel_limits_fast(ys, ms.ny, ms.y0, ms.y1, ms.inv_hy, ms.inv_ly, r0.y, ey, sw.lly, sw.uly);
   const bool fz = subvoxel_limits_fast(zs, ms.nz, ms.z0, ms.z1, ms.inv_hz, ms.inv_lz, r0.z, ez, sw.llz, sw.ulz);
-  cb0 = make_cull_box(r0, step, step_l);
   if (fx && fy && fz) return;
   sw.llx = ll_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
   sw.lly = ll_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
@@ -293,7 +320,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
       const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
       tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
     }
-    const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
+    const double *rec = ms.tri + (int64_t)(int)sv.x * DS_TRI_STRIDE;
     d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
     if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
   }
@@ -312,10 +339,10 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   if (is_min) atomicMin(&W->best_key[owner], key); /* pass B: among equal d the earliest (visit, position) */
   wave_sync();
   if (is_min && key == W->best_key[owner]) { /* pass C: the winner publishes its triangle's normal */
-    /* the record is still in the vector L1: publish E1 x E2 so that the owner does not have to
-     * fetch the triangle before it can reflect ((A-B)x(A-C) == E1 x E2 bit for bit) */
-    const double *rec = ms.tri + (int64_t)(int)sv.x * 9;
-    const V3 nn = cross3(load_v3(rec + 3), load_v3(rec + 6));
+    /* the record is still in the vector L1: publish its unit normal so that the owner does not have to
+     * fetch the triangle before it can reflect */
+    const double *rec = ms.tri + (int64_t)(int)sv.x * DS_TRI_STRIDE;
+    const V3 nn = load_v3(rec + 9);
     double *bn = W->best_n[owner];
     bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
   }
@@ -395,7 +422,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   /* ---- stage 1b: all lanes look the subvoxels up and list the micro-cells the cull box reaches */
   int n_cellq = 0; /* cell tasks queued (wave-uniform; may exceed the capacity: the excess was not written) */
   {
-    const int n = min(W->n_svq, COOP_SVQ_CAP);
+    /* a counter read from LDS is the same in every lane, but only readfirstlane tells the compiler so: the queue
+     * loops then run on scalar compares and branches instead of exec-mask arithmetic, and their counters live
+     * in SGPRs */
+    const int n = __builtin_amdgcn_readfirstlane(min(W->n_svq, COOP_SVQ_CAP));
     const uint2 *svq = coop_svq(W);
     uint2 *cq = coop_cellq(W);
     for (int first = 0; first < n; first += 64) {
@@ -576,12 +606,13 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         /* a trip adds 15 survivors on average and 256 at most: whenever the pool holds 64, its last
          * 64 entries make one full trip of fp64 tests */
         wave_sync();
-        for (int n = min(W->n_surv, COOP_SURV_CAP); n >= 64; n -= 64) flush_survivors(ms, r0, step, W, lane, seen_d, n - 64, 64);
+        for (int n = __builtin_amdgcn_readfirstlane(min(W->n_surv, COOP_SURV_CAP)); n >= 64; n -= 64)
+          flush_survivors(ms, r0, step, W, lane, seen_d, n - 64, 64);
       }
       n_items = start;
     }
     {
-      const int n = min(W->n_surv, COOP_SURV_CAP); /* < 64 */
+      const int n = __builtin_amdgcn_readfirstlane(min(W->n_surv, COOP_SURV_CAP)); /* < 64 */
       if (n > 0) flush_survivors(ms, r0, step, W, lane, seen_d, 0, n);
     }
   }
@@ -600,8 +631,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       iteration_serial(ms, sw, r0, step, xs, ys, zs, best);
       d = best.d;
       if (d <= step_l) {
-        const double *rec = ms.tri + (int64_t)best.tri * 9;
-        n = cross3(load_v3(rec + 3), load_v3(rec + 6));
+        const double *rec = ms.tri + (int64_t)best.tri * DS_TRI_STRIDE;
+        n = load_v3(rec + 9);
       }
     } else {
       const unsigned long long bd = W->best_d[lane];
@@ -616,7 +647,6 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       finished = true; /* check_intersection = False */
     } else {
       const bool reflect = p.perm_prob < rng_uniform_f64(rng);
-      normalize3(n);
       if (reflect)
         reflection(r0, step, d, n, p.eps);
       else

@@ -88,6 +88,14 @@ __global__ __launch_bounds__(256) void unit_kernel(const UnitArgs a) {
         OUT(0) = (double)ll, OUT(1) = (double)ul, OUT(2) = ok ? 1.0 : 0.0;
       }
     } break;
+    case 19: { /* the float32 shortcut of the cooperative kernel: (ll, ul, decided) */
+      const int ns = a.n_xs - 1;
+      int ll = 0, ul = 0;
+      float edge, reach;
+      subvoxel_limits_f32(a.xs[0], (double)ns / (a.xs[ns] - a.xs[0]), IN(0), IN(1), ll, ul, edge, reach);
+      const bool ok = edge < 0.4999f && reach < 1500.0f; /* the acceptance rule of segment_query() */
+      OUT(0) = (double)ll, OUT(1) = (double)ul, OUT(2) = ok ? 1.0 : 0.0;
+    } break;
     case 11: OUT(0) = line_circle_intersection(IN(0), IN(1), IN(2), IN(3), IN(4)); break;
     case 12: {
       const V3 r0 = {IN(0), IN(1), IN(2)}, st = {IN(3), IN(4), IN(5)};

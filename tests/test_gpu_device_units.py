@@ -266,6 +266,11 @@ def test_subvoxel_lookups_reproduce_the_reference_scans(dev, host):
         b = np.concatenate([xs + k * L for k in (-2, -1, 0, 1, 3)])
         x1 = np.concatenate([x1, b, b, np.nextafter(b, np.inf), np.nextafter(b, -np.inf), b[:-1]])
         x2 = np.concatenate([x2, b, np.nextafter(b, np.inf), b, b, b[1:]])
+        # coordinates at 1e-7 ... 1e-3 subvoxel widths from a boundary, on both sides (the float32 shortcut's margin)
+        h = L / n_sv
+        near = np.concatenate([b + s * d * h for d in (1e-7, 1e-6, 3e-5, 9e-5, 1.1e-4, 2e-4, 1e-3) for s in (-1, 1)])
+        x1 = np.concatenate([x1, near, near])
+        x2 = np.concatenate([x2, near + 0.3 * h, near - 0.45 * h])
         for op in (8, 9):
             got, want = dev(op, [x1, x2], 2, xs), host(op, [x1, x2], 2, xs)
             npt.assert_array_equal(got, want)
@@ -273,6 +278,11 @@ def test_subvoxel_lookups_reproduce_the_reference_scans(dev, host):
         ok = fast[2] == 1.0
         assert ok.mean() > 0.99  # the loop-free path decides almost always ...
         npt.assert_array_equal(fast[:2, ok], want[:, ok])  # ... and is right whenever it says so
+        f32 = dev(19, [x1, x2], 3, xs)  # the float32 shortcut tried first: decides unless a coordinate is
+        ok = f32[2] == 1.0              # within 1e-4 subvoxel widths of a boundary, and is right whenever it does
+        n_eq = 5 * len(b) - 1  # the boundary-equal inputs appended above never qualify
+        assert ok[:n].mean() > 0.998 and not ok[n : n + n_eq].any()
+        npt.assert_array_equal(f32[:2, ok], want[:, ok])
     xs = np.linspace(0, 1.0, 11)
     g = dev(8, [np.array([0.25, 0.35, -1.0, 0.95, xs[3], xs[3]]), np.array([0.35, 0.25, 0.05, 7.0, xs[3], xs[4]])], 2, xs)
     npt.assert_array_equal(g.T, [[2, 4], [2, 4], [0, 1], [9, 10], [3, 3], [3, 4]])
