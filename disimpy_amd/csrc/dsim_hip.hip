@@ -246,6 +246,9 @@ struct dsim_sim {
   int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
   int mesh_traversal = 0; /* 0/2 = wavefront-cooperative (clearance map when it pays), 1 = per-lane, 3 = cooperative, never the map, 4 = always */
   unsigned long long *clear_count = nullptr;
+  /* per-walker clocks of the cooperative mesh kernel (run_impl, own_clock) */
+  int32_t *tcur[2] = {nullptr, nullptr};
+  unsigned long long *progress = nullptr; /* {walkers not yet at t_end, time steps they still have to take, most left} */
   double last_clear_frac = 0;
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
   bool sort_ready = false;
@@ -286,6 +289,9 @@ static int ensure_staging(dsim_sim *h, size_t bytes) {
   if (h->staging_bytes >= bytes) return DSIM_OK;
   if (h->staging) (void)hipFree(h->staging);
   if (h->clear_count) (void)hipFree(h->clear_count);
+  for (int b = 0; b < 2; b++)
+    if (h->tcur[b]) (void)hipFree(h->tcur[b]);
+  if (h->progress) (void)hipFree(h->progress);
   h->staging = nullptr;
   h->staging_bytes = 0;
   HIP_TRY(hipMalloc(&h->staging, bytes));
@@ -421,7 +427,7 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
 #endif
     h->grad_src = gradient_source - 1;
   }
-  if (mesh_traversal >= 1 && mesh_traversal <= 4) h->mesh_traversal = mesh_traversal;
+  if (mesh_traversal >= 1 && mesh_traversal <= 5) h->mesh_traversal = mesh_traversal;
   return DSIM_OK;
 }
 
@@ -1102,24 +1108,29 @@ static int ensure_sort_buffers(dsim_sim *h) {
   iota_kernel<<<grid_for(n, 256), 256, 0, h->stream>>>(h->iota, n);
   HIP_TRY(hipGetLastError());
   size_t bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 30, h->stream));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 31, h->stream));
   HIP_TRY(hipMalloc(&h->sort_tmp, bytes));
+  for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&h->tcur[b], n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->progress, 3 * sizeof(unsigned long long)));
   h->sort_tmp_bytes = bytes;
   h->sort_ready = true;
   return DSIM_OK;
 }
 
 /* sort the walkers of the current state buffer by Morton key; flips h->cur */
-static int resort_walkers(dsim_sim *h, bool first) {
+static int resort_walkers(dsim_sim *h, bool first, bool clocks = false, int32_t t_end = 0, bool by_steps_left = false) {
   const int64_t n = h->n;
   const int g = grid_for(n, 256);
   const int c = h->cur, o = 1 - h->cur;
   const DevMesh &dm = h->mesh;
-  morton_key_kernel<<<g, 256, 0, h->stream>>>(h->x[c], h->y[c], h->z[c], n, dm.inv_l[0], dm.inv_l[1], dm.inv_l[2], h->keys[0]);
+  /* the clocks travel with the state buffers: tcur[cur] belongs to x[cur] */
+  morton_key_kernel<<<g, 256, 0, h->stream>>>(h->x[c], h->y[c], h->z[c], n, dm.inv_l[0], dm.inv_l[1], dm.inv_l[2], h->keys[0],
+                                              clocks ? h->tcur[c] : nullptr, t_end, by_steps_left ? 1 : 0);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 30, h->stream));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 31, h->stream));
   gather_state_kernel<<<g, 256, 0, h->stream>>>(h->perm, n, h->x[c], h->y[c], h->z[c], h->s0[c], h->s1[c], h->exc, first ? h->iota : h->orig[h->orig_cur],
-                                                h->x[o], h->y[o], h->z[o], h->s0[o], h->s1[o], h->exc_alt, h->orig[1 - h->orig_cur]);
+                                                h->x[o], h->y[o], h->z[o], h->s0[o], h->s1[o], h->exc_alt, h->orig[1 - h->orig_cur],
+                                                clocks ? h->tcur[c] : nullptr, h->tcur[o]);
   HIP_TRY(hipGetLastError());
   dim3 pg(g, h->M);
   gather_rows_kernel<<<pg, 256, 0, h->stream>>>(h->perm, n, h->phase, h->phase_alt);
@@ -1275,11 +1286,30 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   bool permuted = false;
   /* the time loop; any failure inside leaves through `return`, and the walker order is put back
    * below before the error is reported (getters must never see Morton order) */
+  /* Per-walker clocks (cooperative kernel, re-sorted walkers, nothing recorded): a launch is a budget of passes per
+   * wavefront, not a range of time steps - a lane that needs fewer passes than its neighbours (no reflections) simply
+   * gets further instead of idling until the slowest lane of its wavefront has finished the range.  tcur[i] holds the
+   * next time step of walker i between launches; walkers that have reached t_end are sorted to the end, where their
+   * wavefronts exit at once.  The call returns when every walker is at t_end, so nothing outside sees the clocks. */
+  const bool own_clock = coop4 && resort > 0 && !record && passes == 1 && h->mesh_traversal != 5;
+  long long unfinished = h->n, steps_left = (long long)h->n * (t_end - t_begin), max_left = t_end - t_begin;
+  double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
+  int budget = INT_MAX, launches_left = 1 << 20;
+  if (own_clock) {
+    fill_i32_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->tcur[h->cur], h->n, t_begin);
+    HIP_TRY(hipGetLastError());
+  }
   auto time_loop = [&]() -> int {
-  for (int ca = t_begin; ca < t_end;) {
-    const int cb = resort > 0 ? std::min(t_end, ca + resort) : t_end;
+  for (int ca = t_begin; own_clock ? unfinished > 0 : ca < t_end;) {
+    const int cb = own_clock ? t_end : (resort > 0 ? std::min(t_end, ca + resort) : t_end);
+    if (own_clock) {
+      if (--launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
+      /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
+       * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
+      budget = max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(passes_per_step * resort) + 2;
+    }
     if (resort > 0) {
-      int rc = resort_walkers(h, !permuted);
+      int rc = resort_walkers(h, !permuted, own_clock, t_end, own_clock && budget == INT_MAX && max_left < t_end - t_begin);
       if (rc) return rc;
       permuted = true;
     }
@@ -1313,9 +1343,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     p.s1_out = h->s1[dst];
     p.phase = h->phase;
     p.exc = h->exc;
-    p.t_begin = ta;
+    p.t_begin = own_clock ? t_begin : ta;
     p.t_end = tb;
     p.traj = record ? h->traj : nullptr;
+    p.tcur = own_clock ? h->tcur[h->cur] : nullptr;
+    p.iter_budget = budget;
     for (int pass = 0; pass < passes; pass++) {
       p.m0 = pass * mb;
       p.mc = split_phase ? 0 : std::min(mb, h->M - p.m0);
@@ -1365,6 +1397,23 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     }
     ta = tb;
    }
+    if (own_clock) {
+      HIP_TRY(hipMemsetAsync(h->progress, 0, 3 * sizeof(unsigned long long), h->stream));
+      progress_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->tcur[h->cur], h->n, t_end, h->progress);
+      HIP_TRY(hipGetLastError());
+      unsigned long long pr[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpyAsync(pr, h->progress, sizeof(pr), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      const long long done = steps_left - (long long)pr[1];
+      if (done > 0 && budget != INT_MAX) {
+        const double measured = (double)budget * (double)unfinished / (double)done; /* an upper estimate: finished lanes idle */
+        passes_per_step = std::min(4.0, std::max(1.0, 0.5 * passes_per_step + 0.5 * measured));
+      }
+      unfinished = (long long)pr[0];
+      steps_left = (long long)pr[1];
+      max_left = (long long)pr[2];
+      continue; /* ca stays: the next launch again covers [t_begin, t_end) with the walkers' own clocks */
+    }
     ca = cb;
   }
   return DSIM_OK;

@@ -113,6 +113,11 @@ struct WalkParams {
   double eps, perm_prob;
   MeshDev mesh;
   double *traj; /* walk_kernel_coop4_traj: [t - t_begin][3][n], the positions after every time step of the launch */
+  /* cooperative mesh kernel with per-walker clocks (run_impl, own_clock): tcur[i] = the next time step of walker i
+   * on entry and on exit; the launch ends when every wavefront has run iter_budget passes (walkers inside a step
+   * finish it) or all its walkers have reached t_end.  nullptr: every walker runs [t_begin, t_end). */
+  int32_t *tcur;
+  int iter_budget;
 };
 
 /* ---- one walker, one time step, by substrate -------------------------------- */
@@ -468,15 +473,21 @@ DSD void walk_body(const WalkParams &p) {
         coop->tlast = __builtin_readcyclecounter();
       }
 #endif
+      /* k_lane: the walker's own clock relative to t0.  With p.tcur the clocks persist across launches: a launch
+       * is then a budget of passes per wavefront instead of a range of time steps, so that no lane waits at the
+       * end of a launch for neighbours that needed more passes (walkers in thin processes reflect on most steps,
+       * walkers in the soma hardly ever). */
       int k_lane = 0;
+      if (p.tcur != nullptr && live) k_lane = p.tcur[i] - t0;
       bool in_step = false, clear = false;
       V3 step = {0, 0, 0};
       double sl = 0;
       int64_t iter_idx = 0;
-      for (;;) {
+      for (int passes = 0;; passes++) {
         const bool want = live && k_lane < kt;
-        if (__ballot(want) == 0ULL) break;
-        if (want && !in_step) {
+        const bool may_start = p.tcur == nullptr || passes < p.iter_budget; /* wave-uniform */
+        if (__ballot(want && (in_step || may_start)) == 0ULL) break;
+        if (want && !in_step && may_start) {
           clear = walker_is_clear(p.mesh, r); /* look-ups issued before, consumed after the random step */
           step = random_step(rng, log_tab, cos_tab);
           sl = p.step_l;
@@ -519,6 +530,7 @@ DSD void walk_body(const WalkParams &p) {
         }
         T_MARK(coop, lane, 9);
       }
+      if (p.tcur != nullptr && live) p.tcur[i] = t0 + k_lane;
 #ifdef DSIM_TIMERS
       if (lane == 0)
         for (int q = 0; q < 16; q++) atomicAdd(&dsim_timers[q], coop->tacc[q]);
@@ -787,9 +799,16 @@ DSD uint32_t spread10(uint32_t v) { /* 10 bits -> every third bit */
 /* 30-bit Morton code of the position wrapped into the periodic voxel (1024^3 cells).
  * Only a sort key: approximate arithmetic is fine, results never depend on it. */
 __global__ void morton_key_kernel(const double *x, const double *y, const double *z, int64_t n, double inv_lx, double inv_ly,
-                                  double inv_lz, uint32_t *keys) {
+                                  double inv_lz, uint32_t *keys, const int32_t *tcur, int32_t t_end, int by_steps_left) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (tcur != nullptr && tcur[i] >= t_end) { /* per-walker clocks: walkers that are done go to the end of the order */
+    keys[i] = 0x40000000u;
+    return;
+  }
+  /* last launch of a call (every walker runs to t_end): walkers with a similar number of steps left share wavefronts,
+   * so that no lane idles long for its neighbours; within such a class the order is spatial as usual */
+  const uint32_t cls = by_steps_left && tcur != nullptr ? (uint32_t)min(63, (t_end - tcur[i]) >> 5) : 0u;
   double fx = x[i] * inv_lx, fy = y[i] * inv_ly, fz = z[i] * inv_lz;
   fx -= __builtin_floor(fx);
   fy -= __builtin_floor(fy);
@@ -797,7 +816,32 @@ __global__ void morton_key_kernel(const double *x, const double *y, const double
   uint32_t ix = fx == fx ? (uint32_t)min(1023, max(0, (int)(fx * 1024.0))) : 0u;
   uint32_t iy = fy == fy ? (uint32_t)min(1023, max(0, (int)(fy * 1024.0))) : 0u;
   uint32_t iz = fz == fz ? (uint32_t)min(1023, max(0, (int)(fz * 1024.0))) : 0u;
-  keys[i] = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
+  const uint32_t morton = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
+  keys[i] = by_steps_left ? (cls << 24) | (morton >> 6) : morton;
+}
+
+/* per-walker clocks: {walkers that have not reached t_end, time steps they still have to take, the most any of them has left} */
+__global__ void progress_kernel(const int32_t *tcur, int64_t n, int32_t t_end, unsigned long long *out3) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int left = 0;
+  if (i < n) left = max(0, t_end - tcur[i]);
+  const unsigned long long m = __ballot(left > 0);
+  int sum = left, mx = left;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+    mx = max(mx, __shfl_down(mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && m) {
+    atomicAdd(&out3[0], (unsigned long long)__popcll(m));
+    atomicAdd(&out3[1], (unsigned long long)sum);
+    atomicMax(&out3[2], (unsigned long long)mx);
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t *v, int64_t n, int32_t value) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = value;
 }
 
 __global__ void iota_kernel(int32_t *v, int64_t n) {
@@ -809,10 +853,11 @@ __global__ void iota_kernel(int32_t *v, int64_t n) {
 __global__ void gather_state_kernel(const int32_t *perm, int64_t n, const double *x, const double *y, const double *z,
                                     const uint64_t *s0, const uint64_t *s1, const uint8_t *exc, const int32_t *orig,
                                     double *xo, double *yo, double *zo, uint64_t *s0o, uint64_t *s1o, uint8_t *exco,
-                                    int32_t *origo) {
+                                    int32_t *origo, const int32_t *tcur, int32_t *tcuro) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int32_t j = perm[i];
+  if (tcur != nullptr) tcuro[i] = tcur[j];
   xo[i] = x[j];
   yo[i] = y[j];
   zo[i] = z[j];

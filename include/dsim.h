@@ -211,7 +211,9 @@ int dsim_write_traj_line(const char *path, const double *positions_aos, int64_t 
  * traversed (1 = per lane, 2 = wavefront-cooperative, using the clearance map -
  * walkers farther than a step from every triangle skip the traversal - in the
  * launches that start with >= 40 % of the walkers clear; 3 = never, 4 = always
- * the map).  Results never depend on any of them. */
+ * the map; 5 = as 2, but every launch covers the same range of time steps for all
+ * walkers instead of giving each wavefront a budget of passes - the round-1
+ * scheduling, kept for comparison).  Results never depend on any of them. */
 int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass,
                     int32_t resort_steps, int32_t gradient_source, int32_t mesh_traversal);
 

@@ -55,15 +55,23 @@ def test_neuron_production_shape_resorted_launches(lib, oracle_exact):
     ma = _mesh_arrays(sub)
     ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
     kw = dict(max_iter=1000, epsilon=1e-13)
-    with lib.Sim(n, g, dt, step_l) as sim:  # default tuning: what bench.py runs
-        sim.rng_init_device(123)
-        sim.set_positions(pos0)
-        sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
-        sim.run_mesh(1000, 1e-13, 0.0, 0, T)
-        assert sim.last_run_ms()[1] >= 3 and sim.last_walk_ms()[1] >= 3  # >= 2 re-sort intervals, >= 2 launches
-        c, s, _ = sim.signal()
-        gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
-    _assert_identical(gpu, ref)
+    # default tuning = what bench.py runs: per-walker clocks (a launch is a budget of passes per wavefront; walkers
+    # reach step 2200 in different launches); mesh_traversal 5 = every launch covers the same steps for all walkers;
+    # and the default again in two calls (all walkers are synchronised at every call boundary)
+    for tuning, chunks in ((None, [0, T]), (dict(mesh_traversal=5), [0, T]), (None, [0, 1500, T])):
+        with lib.Sim(n, g, dt, step_l) as sim:
+            if tuning:
+                sim.set_tuning(**tuning)
+            sim.rng_init_device(123)
+            sim.set_positions(pos0)
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+            for t0, t1 in zip(chunks[:-1], chunks[1:]):
+                sim.run_mesh(1000, 1e-13, 0.0, t0, t1)
+            if len(chunks) == 2:
+                assert sim.last_run_ms()[1] >= 3 and sim.last_walk_ms()[1] >= 3  # >= 2 re-sort intervals, >= 2 launches
+            c, s, _ = sim.signal()
+            gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
+        _assert_identical(gpu, ref)
     assert (gpu["pos"].max(axis=0) < sub.voxel_size).all() and (gpu["pos"].min(axis=0) > 0).all()
     del kw
 
