@@ -737,6 +737,59 @@ static void build_clearance_map(const double *vertices, const int64_t *faces, in
   clear_frac = 1.0 - set_bits / ((double)n_sub * F * F * F);
 }
 
+/* Bounding box of the part of a triangle that lies inside micro-cell (a, b, c) of a k^3 grid - the cell inflated by
+ * 1e-6 of its size and, on the border of the grid, extended to infinity, exactly as triangle_reaches_cell() takes it.
+ * A record only has to answer for hits that happen inside ITS cell (a hit point lies in a visited cell in which the
+ * triangle is registered, and it is that cell's record that must survive the box test), so the box of the clipped
+ * triangle is a valid - and for the long slivers of a dendrite's skin far tighter - replacement of the triangle's
+ * own box.  Sutherland-Hodgman clipping in double precision; the result is pushed outwards by another 1e-6 cell
+ * sizes (rounding of the clipping) and intersected with the triangle's box.  Returns false (keep the triangle's box)
+ * when the clipped polygon comes out empty, which only rounding can cause for a registered triangle. */
+static bool clipped_triangle_box(const double *const tv[3], const double org[3], const double scale[3], const int abc[3], int k,
+                                 double lo[3], double hi[3]) {
+  double poly[16][3], tmp[16][3];
+  int n = 3;
+  for (int q = 0; q < 3; q++)
+    for (int ax = 0; ax < 3; ax++) poly[q][ax] = tv[q][ax];
+  for (int ax = 0; ax < 3 && n > 0; ax++) {
+    const double w = 1.0 / scale[ax], m = 1e-6 * w;
+    for (int side = 0; side < 2 && n > 0; side++) {
+      if ((side == 0 && abc[ax] == 0) || (side == 1 && abc[ax] == k - 1)) continue; /* border cell: unbounded */
+      const double bound = side == 0 ? org[ax] + abc[ax] * w - m : org[ax] + (abc[ax] + 1) * w + m;
+      int out = 0;
+      for (int q = 0; q < n; q++) {
+        const double *p0 = poly[q], *p1 = poly[(q + 1) % n];
+        const double d0 = side == 0 ? p0[ax] - bound : bound - p0[ax], d1 = side == 0 ? p1[ax] - bound : bound - p1[ax];
+        if (d0 >= 0) {
+          for (int e = 0; e < 3; e++) tmp[out][e] = p0[e];
+          out++;
+        }
+        if ((d0 >= 0) != (d1 >= 0)) {
+          const double t = d0 / (d0 - d1);
+          for (int e = 0; e < 3; e++) tmp[out][e] = p0[e] + t * (p1[e] - p0[e]);
+          tmp[out][ax] = bound;
+          out++;
+        }
+      }
+      n = out;
+      for (int q = 0; q < n; q++)
+        for (int e = 0; e < 3; e++) poly[q][e] = tmp[q][e];
+    }
+  }
+  if (n == 0) return false;
+  for (int ax = 0; ax < 3; ax++) {
+    const double m = 1e-6 / scale[ax];
+    lo[ax] = hi[ax] = poly[0][ax];
+    for (int q = 1; q < n; q++) {
+      lo[ax] = std::min(lo[ax], poly[q][ax]);
+      hi[ax] = std::max(hi[ax], poly[q][ax]);
+    }
+    lo[ax] -= m;
+    hi[ax] += m;
+  }
+  return true;
+}
+
 static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
                        int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                        const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l) {
@@ -874,10 +927,25 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       sv_micro[s] = make_int2((int)cell_range.size(), lk);
       if (lk == 0) sv_micro[s] = make_int2(-((int)(mrec.size() / 3) + 1), n_s); /* single cell: range inline */
-      for (auto &cl : cells) {
+      for (size_t ci = 0; ci < cells.size(); ci++) {
+        auto &cl = cells[ci];
+        const int abc[3] = {(int)(ci / ((size_t)k * k)), (int)((ci / k) % k), (int)(ci % k)};
         int start = (int)(mrec.size() / 3);
         for (int32_t i : cl) {
-          const float *lo = &lo3[(size_t)(i - begin) * 3], *hi = &hi3[(size_t)(i - begin) * 3];
+          float lo[3], hi[3];
+          for (int ax = 0; ax < 3; ax++) lo[ax] = lo3[(size_t)(i - begin) * 3 + ax], hi[ax] = hi3[(size_t)(i - begin) * 3 + ax];
+          if (k > 1) { /* the box of the triangle's part inside this cell, float32 rounded outwards, never beyond the triangle's own */
+            const int64_t *fc3 = &faces[(size_t)refs[i] * 3];
+            const double *tv[3] = {&vertices[fc3[0] * 3], &vertices[fc3[1] * 3], &vertices[fc3[2] * 3]};
+            double clo[3], chi[3];
+            if (clipped_triangle_box(tv, org, scale, abc, k, clo, chi))
+              for (int ax = 0; ax < 3; ax++) {
+                const float l = std::nextafter((float)clo[ax], -std::numeric_limits<float>::infinity());
+                const float h2 = std::nextafter((float)chi[ax], std::numeric_limits<float>::infinity());
+                lo[ax] = std::max(lo[ax], l);
+                hi[ax] = std::min(hi[ax], h2);
+              }
+          }
           float idx_bits, pos_bits;
           int32_t ti = refs[i];
           memcpy(&idx_bits, &ti, sizeof(float));
@@ -1635,36 +1703,42 @@ static size_t format_py_float(double x, char *out) {
 static int write_traj_lines(FILE *f, int64_t n, int n_lines, const double *base, size_t line_stride, const double *x_off,
                             const double *y_off, const double *z_off, size_t stride) {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw, 32u), n / 2048));
+  const int64_t values = n * n_lines;
+  const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw, 32u), values / 4096));
+  /* the block of lines is cut into n_thr contiguous pieces of (line, walker) pairs; every piece is formatted into a
+   * buffer of its own by one thread - one spawn per block of lines, not per line - and the buffers are written in order */
   std::vector<std::vector<char>> bufs((size_t)n_thr);
-  for (int line = 0; line < n_lines; line++) {
-    const double *px = x_off + (size_t)line * line_stride, *py = y_off + (size_t)line * line_stride, *pz = z_off + (size_t)line * line_stride;
-    auto work = [&](int k) {
-      const int64_t a = n * k / n_thr, b = n * (k + 1) / n_thr;
-      std::vector<char> &buf = bufs[(size_t)k];
-      buf.resize((size_t)(b - a) * 3 * 25 + 2);
-      char *p = buf.data();
-      for (int64_t i = a; i < b; i++) {
-        p += format_py_float(px[(size_t)i * stride], p);
-        *p++ = ' ';
-        p += format_py_float(py[(size_t)i * stride], p);
-        *p++ = ' ';
-        p += format_py_float(pz[(size_t)i * stride], p);
-        *p++ = ' ';
+  auto work = [&](int k) {
+    const int64_t a = values * k / n_thr, b = values * (k + 1) / n_thr;
+    std::vector<char> &buf = bufs[(size_t)k];
+    buf.resize((size_t)(b - a) * 3 * 25 + (size_t)n_lines + 2);
+    char *p = buf.data();
+    int64_t line = a / n, i = a % n;
+    for (int64_t v = a; v < b; v++) {
+      const size_t off = (size_t)line * line_stride + (size_t)i * stride;
+      p += format_py_float(x_off[off], p);
+      *p++ = ' ';
+      p += format_py_float(y_off[off], p);
+      *p++ = ' ';
+      p += format_py_float(z_off[off], p);
+      *p++ = ' ';
+      if (++i == n) {
+        *p++ = '\n';
+        i = 0;
+        line++;
       }
-      if (k == n_thr - 1) *p++ = '\n';
-      buf.resize((size_t)(p - buf.data()));
-    };
-    if (n_thr == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> th;
-      for (int k = 0; k < n_thr; k++) th.emplace_back(work, k);
-      for (auto &t : th) t.join();
     }
-    for (int k = 0; k < n_thr; k++)
-      if (fwrite(bufs[(size_t)k].data(), 1, bufs[(size_t)k].size(), f) != bufs[(size_t)k].size()) return fail(DSIM_ERR_STATE, "trajectories file: write failed");
+    buf.resize((size_t)(p - buf.data()));
+  };
+  if (n_thr == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_thr; k++) th.emplace_back(work, k);
+    for (auto &t : th) t.join();
   }
+  for (int k = 0; k < n_thr; k++)
+    if (fwrite(bufs[(size_t)k].data(), 1, bufs[(size_t)k].size(), f) != bufs[(size_t)k].size()) return fail(DSIM_ERR_STATE, "trajectories file: write failed");
   (void)base;
   return DSIM_OK;
 }
