@@ -203,7 +203,6 @@ struct DevMesh {
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
   float4 *mrec = nullptr;
-  float4 *tri_yz = nullptr;
   int2 *sv_micro = nullptr, *cell_range = nullptr;
   int32_t *clear_idx = nullptr;
   uint32_t *clear_bits = nullptr;
@@ -276,7 +275,6 @@ static void free_mesh(DevMesh &m) {
   if (m.sv_range) (void)hipFree(m.sv_range);
   if (m.tri_idx) (void)hipFree(m.tri_idx);
   if (m.mrec) (void)hipFree(m.mrec);
-  if (m.tri_yz) (void)hipFree(m.tri_yz);
   if (m.sv_micro) (void)hipFree(m.sv_micro);
   if (m.cell_range) (void)hipFree(m.cell_range);
   if (m.clear_idx) (void)hipFree(m.clear_idx);
@@ -971,21 +969,6 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     }
     if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
   }
-  /* (y, z) extent of every triangle, float32 rounded outward by two ulps: cull box of the
-   * +x rays of fill_mesh_kernel */
-  std::vector<float4> tri_yz((size_t)n_faces);
-  for (int64_t f = 0; f < n_faces; f++) {
-    const int64_t *fc = &faces[(size_t)f * 3];
-    float lo[2], hi[2];
-    for (int ax = 1; ax < 3; ax++) {
-      double a = vertices[fc[0] * 3 + ax], b = vertices[fc[1] * 3 + ax], c = vertices[fc[2] * 3 + ax];
-      float l = (float)std::min(a, std::min(b, c)), h = (float)std::max(a, std::max(b, c));
-      const float ninf = -std::numeric_limits<float>::infinity(), pinf = std::numeric_limits<float>::infinity();
-      lo[ax - 1] = std::nextafter(std::nextafter(std::nextafter(l, ninf), ninf), ninf);
-      hi[ax - 1] = std::nextafter(std::nextafter(std::nextafter(h, pinf), pinf), pinf);
-    }
-    tri_yz[f] = make_float4(lo[0], lo[1], hi[0], hi[1]);
-  }
   std::vector<double> bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
   bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
@@ -1006,8 +989,6 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&dm.tri_yz, tri_yz.size() * sizeof(float4)));
-  HIP_TRY(hipMemcpyAsync(dm.tri_yz, tri_yz.data(), tri_yz.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMalloc(&dm.mrec, mrec.size() * sizeof(float4)));
   HIP_TRY(hipMalloc(&dm.sv_micro, sv_micro.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.cell_range, cell_range.size() * sizeof(int2)));
@@ -1041,7 +1022,6 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
   m.mrec = dm.mrec;
-  m.tri_yz = dm.tri_yz;
   m.sv_micro = dm.sv_micro;
   m.cell_range = dm.cell_range;
   m.bounds = dm.bounds;
@@ -1848,35 +1828,21 @@ extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, do
 
 /* -------------------------------------------------------------- fill_mesh --- */
 
-__global__ void fill_inf_kernel(double *px, double *py, double *pz, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    px[i] = DS_INF;
-    py[i] = DS_INF;
-    pz[i] = DS_INF;
-  }
-}
-
-__global__ void fill_flag_kernel(const double *px, int64_t n, int32_t *flag) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = px[i] != DS_INF ? 1 : 0;
-}
-
-/* accepted point i of this launch goes to row have + prefix[i] (rows beyond n are dropped) */
+/* accepted point i of this launch goes to row have + prefix[i] (rows beyond n are dropped); the last thread leaves
+ * the new count in the other slot of `have` (two slots, alternating, so that nobody reads what it writes) */
 __global__ void fill_scatter_kernel(const double *px, const double *py, const double *pz, const int32_t *flag, const int32_t *pref,
-                                    int64_t n, const int64_t *have, double *out) {
+                                    int64_t n, const int64_t *have_in, int64_t *have_out, double *out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !flag[i]) return;
-  int64_t row = *have + pref[i];
+  if (i >= n) return;
+  const int64_t base = *have_in;
+  if (i == n - 1) *have_out = base + pref[i] + flag[i];
+  if (!flag[i]) return;
+  int64_t row = base + pref[i];
   if (row < n) {
     out[row * 3] = px[i];
     out[row * 3 + 1] = py[i];
     out[row * 3 + 2] = pz[i];
   }
-}
-
-__global__ void fill_count_kernel(const int32_t *flag, const int32_t *pref, int64_t n, int64_t *have) {
-  *have += (int64_t)pref[n - 1] + flag[n - 1];
 }
 
 extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const double *vertices, int64_t n_vertices,
@@ -1893,7 +1859,10 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   DevMesh dm;
   double *px = nullptr, *py = nullptr, *pz = nullptr;
   uint64_t *s0 = nullptr, *s1 = nullptr, *cols = nullptr;
-  int32_t *d_col_start = nullptr, *d_col_x = nullptr;
+  int32_t *d_col_start = nullptr;
+  int2 *d_col_ent = nullptr, *d_ent = nullptr, *d_mcol = nullptr, *d_ment = nullptr;
+  float4 *d_ent_yz = nullptr, *d_ment_yz = nullptr;
+  int32_t *d_mstart = nullptr;
   int rc = upload_mesh(dm, stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, 0.0);
   auto cleanup = [&]() {
     free_mesh(dm);
@@ -1904,7 +1873,13 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
     if (s1) (void)hipFree(s1);
     if (cols) (void)hipFree(cols);
     if (d_col_start) (void)hipFree(d_col_start);
-    if (d_col_x) (void)hipFree(d_col_x);
+    if (d_col_ent) (void)hipFree(d_col_ent);
+    if (d_ent) (void)hipFree(d_ent);
+    if (d_ent_yz) (void)hipFree(d_ent_yz);
+    if (d_mcol) (void)hipFree(d_mcol);
+    if (d_mstart) (void)hipFree(d_mstart);
+    if (d_ment) (void)hipFree(d_ment);
+    if (d_ment_yz) (void)hipFree(d_ment_yz);
     (void)hipStreamDestroy(stream);
   };
 #define FILL_TRY(expr)                                                                     \
@@ -1934,28 +1909,132 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   const int grid = grid_for(n_points, 256);
   rng_init_kernel<<<grid, 256, 0, stream>>>(sd.s0, sd.s1, 0, n_points, cols, jt.levels, s0, s1);
   FILL_TRY(hipGetLastError());
-  /* per (y, z) column the x indices of the non-empty subvoxels, ascending (see FillParams) */
+  /* (y, z) extent of every triangle, float32 rounded outward by three ulps: cull box of the
+   * +x rays of fill_mesh_kernel */
+  std::vector<float4> h_tri_yz((size_t)n_faces);
+  for (int64_t f = 0; f < n_faces; f++) {
+    const int64_t *fc = &faces[(size_t)f * 3];
+    float lo[2], hi[2];
+    for (int ax = 1; ax < 3; ax++) {
+      double a = vertices[fc[0] * 3 + ax], b = vertices[fc[1] * 3 + ax], c = vertices[fc[2] * 3 + ax];
+      float l = (float)std::min(a, std::min(b, c)), h = (float)std::max(a, std::max(b, c));
+      const float ninf = -std::numeric_limits<float>::infinity(), pinf = std::numeric_limits<float>::infinity();
+      lo[ax - 1] = std::nextafter(std::nextafter(std::nextafter(l, ninf), ninf), ninf);
+      hi[ax - 1] = std::nextafter(std::nextafter(std::nextafter(h, pinf), pinf), pinf);
+    }
+    h_tri_yz[f] = make_float4(lo[0], lo[1], hi[0], hi[1]);
+  }
+  /* the fill kernel's index (see FillParams): per (y, z) column the non-empty subvoxels in ascending x, and per
+   * list entry the triangle, where it was last met in the column, and its (y, z) extent */
   {
     const int nx = dm.nx, ny = dm.ny, nz = dm.nz;
-    std::vector<int32_t> col_start((size_t)ny * nz + 1, 0), col_x;
+    std::vector<int32_t> col_start((size_t)ny * nz + 1, 0), last_x((size_t)std::max<int64_t>(n_faces, 1), -1), touched;
+    std::vector<int2> col_ent, ent;
+    std::vector<float4> ent_yz;
+    std::vector<int32_t> ent_x; /* subvoxel x of every entry */
+    ent.reserve((size_t)n_refs);
+    ent_yz.reserve((size_t)n_refs);
     for (int y = 0; y < ny; y++)
       for (int z = 0; z < nz; z++) {
-        col_start[(size_t)y * nz + z] = (int32_t)col_x.size();
+        col_start[(size_t)y * nz + z] = (int32_t)col_ent.size();
         for (int x = 0; x < nx; x++) {
           const int64_t sv = ((int64_t)x * ny + y) * nz + z;
-          if (subvoxel_indices[sv * 2 + 1] > subvoxel_indices[sv * 2]) col_x.push_back(x);
+          const int64_t lo = subvoxel_indices[sv * 2], hi = subvoxel_indices[sv * 2 + 1];
+          if (hi <= lo) continue;
+          col_ent.push_back(make_int2(x, (int)ent.size()));
+          for (int64_t i = lo; i < hi; i++) {
+            const int64_t ti = triangle_indices[i];
+            if (i < 0 || i >= n_refs || ti < 0 || ti >= n_faces) {
+              cleanup();
+              return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: subvoxel list entry %lld out of range", (long long)i);
+            }
+            ent.push_back(make_int2((int)ti, last_x[ti]));
+            ent_yz.push_back(h_tri_yz[ti]);
+            ent_x.push_back(x);
+            if (last_x[ti] < 0) touched.push_back((int32_t)ti);
+            last_x[ti] = x;
+          }
         }
+        for (int32_t ti : touched) last_x[ti] = -1;
+        touched.clear();
       }
-    col_start[(size_t)ny * nz] = (int32_t)col_x.size();
-    if (col_x.empty()) col_x.push_back(0);
+    col_start[(size_t)ny * nz] = (int32_t)col_ent.size();
+    col_ent.push_back(make_int2(nx, (int)ent.size())); /* sentinel: end of the last list */
+    if (ent.empty()) {
+      ent.push_back(make_int2(0, -1));
+      ent_yz.push_back(make_float4(0, 0, 0, 0));
+    }
+    /* the bucketed copy (FillParams::mcol): G x G buckets over the cross-section of every non-empty column,
+     * entries in descending x; a triangle goes into every bucket its float32 extent (already rounded outward)
+     * reaches, widened by 1e-6 bucket widths against the rounding of the kernel's own bucket arithmetic */
+    std::vector<int2> mcol((size_t)ny * nz, make_int2(-1, 0)), ment;
+    std::vector<int32_t> mstart;
+    std::vector<float4> ment_yz;
+    {
+      std::vector<std::vector<int32_t>> buckets;
+      for (int y = 0; y < ny; y++)
+        for (int z = 0; z < nz; z++) {
+          const size_t c = (size_t)y * nz + z;
+          if (col_start[c + 1] == col_start[c]) continue;
+          const int e0 = col_ent[col_start[c]].y;
+          const int e1 = (size_t)col_start[c + 1] < col_ent.size() ? col_ent[col_start[c + 1]].y : (int)ent.size();
+          const int n_e = e1 - e0;
+          const int G = n_e <= 8 ? 1 : (n_e <= 48 ? 4 : (n_e <= 400 ? 8 : 16));
+          buckets.assign((size_t)G * G, {});
+          const double sy = (double)G * dm.inv_h[1], sz = (double)G * dm.inv_h[2];
+          for (int i = e1 - 1; i >= e0; i--) { /* descending x (ascending order reversed) */
+            const float4 q = ent_yz[i];
+            auto cell = [&](double v, double o, double sc, double d) {
+              const double t = std::floor((v - o) * sc + d);
+              return (int)std::min((double)(G - 1), std::max(0.0, t));
+            };
+            const int y0 = cell(q.x, ys[y], sy, -1e-6), y1 = cell(q.z, ys[y], sy, 1e-6);
+            const int z0 = cell(q.y, zs[z], sz, -1e-6), z1 = cell(q.w, zs[z], sz, 1e-6);
+            for (int a = y0; a <= y1; a++)
+              for (int b = z0; b <= z1; b++) buckets[(size_t)a * G + b].push_back(i);
+          }
+          mcol[c] = make_int2((int)mstart.size(), G);
+          for (auto &bk : buckets) {
+            mstart.push_back((int32_t)ment.size());
+            for (int32_t i : bk) {
+              ment.push_back(make_int2(ent[i].x, (ent_x[i] << 16) | (ent[i].y + 1)));
+              ment_yz.push_back(ent_yz[i]);
+            }
+          }
+          mstart.push_back((int32_t)ment.size()); /* end of the column's last bucket */
+        }
+      if (mstart.empty()) mstart.push_back(0);
+      if (ment.empty()) {
+        ment.push_back(make_int2(0, 0));
+        ment_yz.push_back(make_float4(0, 0, 0, 0));
+      }
+    }
+    FILL_TRY(hipMalloc(&d_mcol, mcol.size() * sizeof(int2)));
+    FILL_TRY(hipMalloc(&d_mstart, mstart.size() * sizeof(int32_t)));
+    FILL_TRY(hipMalloc(&d_ment, ment.size() * sizeof(int2)));
+    FILL_TRY(hipMalloc(&d_ment_yz, ment_yz.size() * sizeof(float4)));
+    FILL_TRY(hipMemcpy(d_mcol, mcol.data(), mcol.size() * sizeof(int2), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_mstart, mstart.data(), mstart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_ment, ment.data(), ment.size() * sizeof(int2), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_ment_yz, ment_yz.data(), ment_yz.size() * sizeof(float4), hipMemcpyHostToDevice));
     FILL_TRY(hipMalloc(&d_col_start, col_start.size() * sizeof(int32_t)));
-    FILL_TRY(hipMalloc(&d_col_x, col_x.size() * sizeof(int32_t)));
+    FILL_TRY(hipMalloc(&d_col_ent, col_ent.size() * sizeof(int2)));
+    FILL_TRY(hipMalloc(&d_ent, ent.size() * sizeof(int2)));
+    FILL_TRY(hipMalloc(&d_ent_yz, ent_yz.size() * sizeof(float4)));
     FILL_TRY(hipMemcpy(d_col_start, col_start.data(), col_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_col_x, col_x.data(), col_x.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_col_ent, col_ent.data(), col_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_ent_yz, ent_yz.data(), ent_yz.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
   FillParams fp;
   fp.col_start = d_col_start;
-  fp.col_x = d_col_x;
+  fp.col_ent = d_col_ent;
+  fp.ent = d_ent;
+  fp.ent_yz = d_ent_yz;
+  fp.mcol = d_mcol;
+  fp.mstart = d_mstart;
+  fp.ment = d_ment;
+  fp.ment_yz = d_ment_yz;
   fp.n_points = n_points;
   fp.px = px;
   fp.py = py;
@@ -1996,31 +2075,38 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   } while (0)
   FILL_TRY2(hipMalloc(&d_flag, n_points * sizeof(int32_t)));
   FILL_TRY2(hipMalloc(&d_pref, n_points * sizeof(int32_t)));
-  FILL_TRY2(hipMalloc(&d_have, sizeof(int64_t)));
+  FILL_TRY2(hipMalloc(&d_have, 2 * sizeof(int64_t)));
   FILL_TRY2(hipMalloc(&d_out, (size_t)n_points * 3 * sizeof(double)));
-  FILL_TRY2(hipMemsetAsync(d_have, 0, sizeof(int64_t), stream));
+  FILL_TRY2(hipMemsetAsync(d_have, 0, 2 * sizeof(int64_t), stream));
   FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
   FILL_TRY2(hipMalloc(&d_tmp, tmp_bytes));
-  int64_t have = 0;
-  int launches = 0;
+  fp.flag = d_flag;
+  /* The running count is read back after a BATCH of launches: a launch past the n-th accepted point only
+   * produces rows that the scatter drops (and advances RNG states nobody reads again), so running a few too many
+   * is harmless; the batch is sized from the acceptance rate seen so far so that the stream is not drained
+   * after each of the ~1/rate launches a thin structure needs (the neuron: ~4000). */
+  int64_t have = 0, launches = 0, batch = 1;
   while (have < n_points) {
-    if (++launches > 1000000) {
-      cleanup2();
-      return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
+    for (int64_t k = 0; k < batch; k++) {
+      if (++launches > 1000000) {
+        cleanup2();
+        return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
+      }
+      fill_mesh_kernel<<<grid, 256, lds, stream>>>(fp);
+      FILL_TRY2(hipGetLastError());
+      FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
+      fill_scatter_kernel<<<grid, 256, 0, stream>>>(px, py, pz, d_flag, d_pref, n_points, d_have + (launches & 1), d_have + ((launches + 1) & 1), d_out);
+      FILL_TRY2(hipGetLastError());
     }
-    fill_inf_kernel<<<grid, 256, 0, stream>>>(px, py, pz, n_points);
-    FILL_TRY2(hipGetLastError());
-    fill_mesh_kernel<<<grid, 256, lds, stream>>>(fp);
-    FILL_TRY2(hipGetLastError());
-    fill_flag_kernel<<<grid, 256, 0, stream>>>(px, n_points, d_flag);
-    FILL_TRY2(hipGetLastError());
-    FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
-    fill_scatter_kernel<<<grid, 256, 0, stream>>>(px, py, pz, d_flag, d_pref, n_points, d_have, d_out);
-    FILL_TRY2(hipGetLastError());
-    fill_count_kernel<<<1, 1, 0, stream>>>(d_flag, d_pref, n_points, d_have);
-    FILL_TRY2(hipGetLastError());
-    FILL_TRY2(hipMemcpyAsync(&have, d_have, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    FILL_TRY2(hipMemcpyAsync(&have, d_have + ((launches + 1) & 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     FILL_TRY2(hipStreamSynchronize(stream));
+    if (have > 0 && have < n_points) {
+      const double per_launch = (double)have / (double)launches;
+      const double left = (double)(n_points - have) / per_launch;
+      batch = (int64_t)std::min(64.0, std::max(1.0, std::floor(left * 0.9)));
+    } else if (have == 0) {
+      batch = std::min<int64_t>(batch * 2, 64);
+    }
   }
   FILL_TRY2(hipMemcpyAsync(out_points, d_out, (size_t)n_points * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
   FILL_TRY2(hipStreamSynchronize(stream));

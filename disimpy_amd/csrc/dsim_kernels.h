@@ -78,7 +78,6 @@ struct MeshDev {
   const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
                               AABB rounded outward, float32 supporting plane n.x = c, triangle index,
                               position in the reference's list */
-  const float4 *tri_yz;    /* [n_faces]     {miny minz maxy maxz} float32, rounded outward (fill kernel) */
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   /* clearance map (dsim_hip.hip, build_clearance_map): every subvoxel is cut into F^3 fine cells, F = 1 << clear_lf;
    * a set bit = some triangle (of any periodic image) comes within one step length (+ margins) of some point of
@@ -895,21 +894,79 @@ __global__ void scatter_rows_kernel(const int32_t *orig, int64_t n, const double
 /* ---- _cuda_fill_mesh (simulations.py:421-502) ------------------------------------ */
 
 struct FillParams {
-  /* per (y, z) column of the index: the x coordinates of its NON-EMPTY subvoxels in ascending order,
-   * col_x[col_start[c] .. col_start[c + 1]).  A +x ray only ever walks along one column, and on a sparse mesh
-   * (the neuron: 1.8 % of the subvoxels hold triangles) almost all of the ~nx/2 subvoxels it crosses are empty:
-   * skipping them changes neither the triangles met nor their order. */
-  const int32_t *col_start, *col_x;
+  /* The fill kernel's own index of the (possibly "stripped") subvoxel lists, built by dsim_fill_mesh:
+   *  - per (y, z) column the NON-EMPTY subvoxels in ascending x: col_ent[col_start[c] .. col_start[c + 1]) =
+   *    {x, first entry}; the entries of one subvoxel end where those of the next element begin (sentinel at the
+   *    end).  A +x ray only ever walks along one column, and on a sparse mesh (the neuron: 1.8 % of the subvoxels
+   *    hold triangles) almost all of the ~nx/2 subvoxels it crosses are empty: skipping them changes neither the
+   *    triangles met nor their order;
+   *  - per entry {triangle, prev} and the triangle's (y, z) extent.  `prev` = the largest x' <= x at which the same
+   *    triangle occurs EARLIER in this column's visiting order (an earlier position of the same list counts as
+   *    x' = x), -1 if none.  The reference keeps the triangles it has hit in a 1000-slot local array and skips a
+   *    triangle that is already there (simulations.py:484-492); the same point, ray and triangle give the same
+   *    answer at every occurrence, and a ray that starts in subvoxel llx visits all of the column's subvoxels
+   *    from llx on, so "already hit" == "occurs earlier at some x' >= llx" == "prev >= llx".  No per-thread
+   *    array: the kernel needs no scratch memory and runs at full occupancy. */
+  const int32_t *col_start;
+  const int2 *col_ent;
+  const int2 *ent;
+  const float4 *ent_yz;
+  /* The same entries once more, bucketed by where in the column's (y, z) cross-section the triangle lies: a +x
+   * ray keeps its (y, z), so only the triangles whose (y, z) extent holds the point can be met, and a triangle
+   * of a fine mesh covers a few per cent of a subvoxel's cross-section.  mcol[c] = {first bucket, G}: the
+   * column is cut into G x G buckets, bucket b holds ment[mstart[b] .. mstart[b + 1]) = {triangle,
+   * x << 16 | (prev + 1)} in DESCENDING x (the ray's subvoxels are the column's tail from llx on, so the walk
+   * starts at the far end and stops at the first x < llx), ment_yz the extents.  Only the NUMBER of distinct
+   * triangles met matters (its parity), not the order - except for the reference's give-up rule at 1000 hits,
+   * for which the kernel falls back to the reference's own order (fill_count_reference_order). */
+  const int2 *mcol;
+  const int32_t *mstart;
+  const int2 *ment;
+  const float4 *ment_yz;
   int64_t n_points;
-  double *px, *py, *pz; /* +inf where no point has been accepted yet */
+  double *px, *py, *pz; /* written where flag = 1 */
+  int32_t *flag;        /* 1 = the candidate of this thread was accepted in this launch */
   uint64_t *s0, *s1;
   int intra;
   double voxel[3];
-  MeshDev mesh; /* tri_idx / sv_range may be the "stripped" index of non-periodic substrates */
+  MeshDev mesh;
 };
 
 #define FILL_MAX_HITS 1000
 
+/* The reference's loop (simulations.py:461-492) over one column in its own order; returns the number of distinct
+ * triangles met, or -1 when the sample is abandoned (:478-479: the 1000-slot list is full and another list entry
+ * follows). */
+DSD int fill_count_reference_order(const FillParams &p, const V3 &pt, int llx, int ulx, int lly, int uly, int llz, int ulz) {
+  const MeshDev &ms = p.mesh;
+  const V3 ray = {1.0, 0.0, 0.0};
+  const float fy = (float)pt.y, fz = (float)pt.z;
+  int n_hits = 0;
+  for (int y = lly; y < uly; y++)
+    for (int z = llz; z < ulz; z++) {
+      const int col = y * ms.nz + z;
+      for (int e = p.col_start[col]; e < p.col_start[col + 1]; e++) {
+        const int2 ce = p.col_ent[e];
+        if (ce.x < llx) continue;
+        if (ce.x >= ulx) break;
+        const int end = p.col_ent[e + 1].y;
+        for (int i = ce.y; i < end; i++) {
+          if (n_hits >= FILL_MAX_HITS) return -1;
+          const int2 en = p.ent[i];
+          const float4 yz = p.ent_yz[i];
+          if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
+          if (en.y >= llx) continue; /* met before on this ray: counted there if it was a hit */
+          const double *rec = ms.tri + (int64_t)en.x * DS_TRI_STRIDE;
+          double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
+          if (d > 0) n_hits++;
+        }
+      }
+    }
+  return n_hits;
+}
+
+/* One candidate point per thread per launch (simulations.py:421-502, launched from :560-579 with a fresh all-inf
+ * `points` array every time, so every thread draws in every launch). */
 __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
   extern __shared__ double lds[];
   const int n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
@@ -917,7 +974,7 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
   __syncthreads();
   const double *xs = lds, *ys = lds + p.mesh.nx + 1, *zs = lds + p.mesh.nx + p.mesh.ny + 2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= p.n_points || p.px[tid] != DS_INF) return;
+  if (tid >= p.n_points) return;
   Rng rng = {p.s0[tid], p.s1[tid]};
   V3 pt;
   pt.x = rng_uniform_f64(rng) * p.voxel[0];
@@ -928,50 +985,45 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
   const V3 ray = {1.0, 0.0, 0.0};
   const MeshDev &ms = p.mesh;
   /* non-periodic lookups (:455-460): ll on min(p, p+ray) = p, ul on max = p+ray */
-  int llx = ll_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x);
-  int lly = ll_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
-  int llz = ll_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
-  int ulx = ul_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x + ray.x);
-  int uly = ul_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
-  int ulz = ul_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+  const int llx = ll_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x);
+  const int lly = ll_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
+  const int llz = ll_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+  const int ulx = ul_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x + ray.x);
+  const int uly = ul_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
+  const int ulz = ul_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+  /* The y and z ranges of a +x ray hold ONE subvoxel each, or none when the point sits exactly on a boundary
+   * (ul <= ll + 1 for a degenerate interval): one column of the index, or no triangle at all. */
   int n_hits = 0;
-  int32_t hits[FILL_MAX_HITS]; /* private (scratch) memory, like the reference's cuda.local.array(1000) */
-  const float fy = (float)pt.y, fz = (float)pt.z;
-  /* the reference's loop order is x, y, z (:461-463); y and z ranges of a +x ray hold one subvoxel each unless
-   * the point sits exactly on a boundary (then they are empty or the loop below still visits x-major per column -
-   * the set of triangles met is the same and only their count matters) */
-  for (int y = lly; y < uly; y++)
-    for (int z = llz; z < ulz; z++) {
-      const int col = y * ms.nz + z;
-      for (int e = p.col_start[col]; e < p.col_start[col + 1]; e++) {
-        const int x = p.col_x[e];
-        if (x < llx) continue;
-        if (x >= ulx) break;
-        int sv = (x * ms.ny + y) * ms.nz + z;
-        int2 range = ms.sv_range[sv];
-        for (int i = range.x; i < range.y; i++) {
-          if (n_hits >= FILL_MAX_HITS) return; /* :478-479: sample abandoned */
-          int ti = ms.tri_idx[i];
-          /* a +x ray can only meet a triangle whose (y, z) extent holds the point: skipping the
-           * others cannot change the hit count (the fp64 test would return NaN for them) */
-          const float4 yz = ms.tri_yz[ti];
-          if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
-          const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
-          double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
-          if (d > 0) {
-            bool already = false;
-            for (int j = 0; j < n_hits; j++)
-              if (hits[j] == ti) {
-                already = true;
-                break;
-              }
-            if (!already) hits[n_hits++] = ti;
-          }
-        }
+  if (uly - lly == 1 && ulz - llz == 1) {
+    const int2 mc = p.mcol[lly * ms.nz + llz];
+    if (mc.x >= 0) {
+      const int G = mc.y;
+      int iy = (int)((pt.y - ys[lly]) * ((double)G * ms.inv_hy)), iz = (int)((pt.z - zs[llz]) * ((double)G * ms.inv_hz));
+      iy = min(max(iy, 0), G - 1), iz = min(max(iz, 0), G - 1);
+      const int b = mc.x + iy * G + iz;
+      const float fy = (float)pt.y, fz = (float)pt.z;
+      const int end = p.mstart[b + 1];
+      for (int i = p.mstart[b]; i < end; i++) {
+        const int2 en = p.ment[i];
+        const int x = en.y >> 16, prev = (en.y & 0xffff) - 1;
+        if (x < llx) break; /* descending x: the rest of the bucket lies behind the point */
+        if (x >= ulx) continue;
+        const float4 yz = p.ment_yz[i];
+        if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
+        if (prev >= llx) continue; /* the same triangle is listed at a nearer x of this ray as well: counted there */
+        const double *rec = ms.tri + (int64_t)en.x * DS_TRI_STRIDE;
+        double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
+        if (d > 0) n_hits++;
       }
     }
-  bool inside = (n_hits & 1) == 1;
-  if (p.intra ? inside : !inside) {
+  } else if (uly > lly && ulz > llz) {
+    n_hits = FILL_MAX_HITS; /* cannot happen (see above); the reference's loop decides */
+  }
+  if (n_hits >= FILL_MAX_HITS) n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, uly, llz, ulz);
+  const bool inside = (n_hits & 1) == 1;
+  const bool accept = n_hits >= 0 && (p.intra ? inside : !inside);
+  p.flag[tid] = accept ? 1 : 0;
+  if (accept) {
     p.px[tid] = pt.x;
     p.py[tid] = pt.y;
     p.pz[tid] = pt.z;

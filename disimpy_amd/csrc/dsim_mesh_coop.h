@@ -447,6 +447,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
                     __shfl(cb0.hx, owner, 64), __shfl(cb0.hy, owner, 64), __shfl(cb0.hz, owner, 64), __shfl(cb0.tau, owner, 64)};
       box_from_segment(cb);
       const bool has = mg.x != 0 && !ABLATE(1); /* not an empty subvoxel (or no task for this lane) */
+      if (has) {
+        STAT_LANE(2);
+        STAT_WAVE(2);
+      }
       int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
       if (mg.x > 0 && !ABLATE(1)) {
         if ((e.x >> 14) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
@@ -513,6 +517,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           const int2 *src = inl ? ms.sv_micro + (e.y & 0x7fffffffu) : ms.cell_range + e.y;
           cr = *src;
           if (inl) cr = make_int2(-cr.x - 1, -cr.x - 1 + cr.y);
+        }
+        if (e.x != 0xffffffffu) {
+          STAT_LANE(5);
+          STAT_WAVE(5);
         }
         const int cnt = ABLATE(2) ? 0 : max(0, cr.y - cr.x);
         const int nb = (cnt + 3) >> 2;

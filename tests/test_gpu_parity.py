@@ -495,6 +495,23 @@ def test_fill_mesh_identical_to_oracle(lib, oracle_exact, periodic, intra):
         assert d.min() > 0.9 * r.min()
 
 
+@pytest.mark.parametrize("intra", [True, False])
+def test_fill_mesh_neuron_identical_to_oracle(lib, oracle_exact, intra):
+    """The reference's rejection sampler on its hardest case: the neuron fills 0.025 % of its voxel, so a run is
+    thousands of launches (the library reads the count back once per batch of them), its triangles are listed in
+    up to six subvoxels of a column (the kernel replaces the reference's 1000-slot list of met triangles by a
+    precomputed "met before on this ray" relation), and most columns of the index are empty."""
+    from disimpy_amd import simulations, substrates
+
+    m = golden("neuron_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), True, init_pos="intra", quiet=True)
+    n = 3000 if intra else 20000
+    got = simulations._fill_mesh(n, sub, intra, 123)
+    g = oracle_exact.geom(MESH, mesh=_mesh_arrays(sub))
+    want = oracle_exact.fill_mesh(n, g, sub.voxel_size, intra, 123, max_launches=100000)
+    npt.assert_array_equal(got, want)
+
+
 # --------------------------------------------------------------------- signal
 
 

@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
-NAMES = ["reflect-loop iterations", "subvoxels visited", "non-empty subvoxels", "micro-cells visited",
-         "record batches (4)", "records examined", "AABB pass -> fp64 test", "hits (reflections)",
+NAMES = ["reflect-loop iterations", "subvoxels visited", "non-empty subvoxels", "non-empty micro-cells",
+         "record batches (4)", "cell tasks (incl. empty cells)", "AABB pass -> fp64 test", "hits (reflections)",
          "coop: cell scanned serially", "coop: survivor overflow redo", "coop: whole iteration serial"]
 
 
