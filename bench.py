@@ -287,7 +287,11 @@ def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
             simulations._run_range(sim, sub, frames, 1000, 1e-13, 0, T)
             run_ms.append(sim.last_run_ms()[0])
             ms, nl = sim.last_walk_ms()
-            walk_ms.append(ms)
+            try:
+                busy, streams = sim.last_walk_busy_ms()
+            except Exception:  # a development build (DSIM_LIB) from before the entry point existed
+                busy, streams = ms, 1
+            walk_ms.append((ms, busy, streams))
             launches.append(nl)
             c, s, nexc = sim.signal()
         else:  # a rank without walkers still takes part in the collective
@@ -365,7 +369,7 @@ def secondary_rates(args, device):
         el, walk_ms, _, _, sig = run_steps(sim, sub, w["frames"], T, 2, None, device, lambda: None)
         sim.close()
         out[name] = {"workload": w["label"], "value": n * T * 2 / el, "unit": "spin-steps/s",
-                     "walk_kernel_spin_steps_per_s": n * T / (float(np.mean(walk_ms)) * 1e-3)}
+                     "walk_kernel_spin_steps_per_s": n * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)}
     return out
 
 
@@ -493,34 +497,42 @@ def main(argv=None):
 
     value = float(n_total) * T * args.steps / elapsed
     # ---- roofline of the dominant kernel (rank 0's shard; every shard runs the same kernel) ----------
+    # walk_ms holds, per step, (sum of the launch durations, time with at least one launch running, streams): a
+    # large mesh shard runs as two halves on two streams whose launches overlap; rates follow from the busy time,
+    # the average launch duration (what a kernel trace reports) from the sum
     n_launch = max(1, launches[-1]) if launches else 1
-    walk_ms_step = float(np.mean(walk_ms)) if walk_ms else float("nan")
-    avg_launch_ms = walk_ms_step / n_launch
+    walk_sum_step = float(np.mean([m[0] for m in walk_ms])) if walk_ms else float("nan")
+    walk_ms_step = float(np.mean([m[1] for m in walk_ms])) if walk_ms else float("nan")
+    streams = int(walk_ms[-1][2]) if walk_ms else 1
+    avg_launch_ms = walk_sum_step / n_launch
     wave_steps_per_s = -(-n_local // 64) * T / (walk_ms_step * 1e-3)
     meas_per_launch = min(M, 32 if not args.meas_per_pass else args.meas_per_pass)
     passes = -(-M // meas_per_launch)
     steps_per_launch = T * passes / n_launch
     alg_bytes_per_launch = (80.0 + 16.0 * meas_per_launch) * n_local * steps_per_launch
-    alg_gbs = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    alg_gbs = alg_bytes_per_launch * n_launch / (walk_ms_step * 1e-3) / 1e9
     prof = profile_entry(args.workload) or {}
     valu_ws = prof.get("valu_per_wave_step")
     traffic = prof.get("hbm_bytes_per_walker_launch")  # measured HBM bytes per walker and launch (state in + out + misses)
-    traffic = traffic * n_local if traffic else None
+    traffic = traffic * n_local / streams if traffic else None
+    hbm_gbs = (traffic * n_launch / (walk_ms_step * 1e-3) / 1e9) if traffic else None
     achieved = valu_ws * wave_steps_per_s if valu_ws else None
     roofline = {
         "bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instr/s",
         "frac": (achieved / VALU_PEAK) if achieved else None,
         "formula": "VALU wave-instructions per wavefront-step (rocprofv3 SQ_INSTS_VALU / wavefront-steps, "
-                   "profiles/) x wavefront-steps/s (HIP events around the walk kernel in this run) / "
+                   "profiles/) x wavefront-steps/s (HIP events around every launch of the walk kernel in this run; "
+                   "time with at least one launch running when the shard's two halves overlap on two streams) / "
                    "(1024 SIMDs x 2.4e9 Hz / 4 cycles per wave64 instruction)",
         "kernel": kernel_name(sub, M, args), "valu_per_wave_step": valu_ws, "salu_per_wave_step": prof.get("salu_per_wave_step"),
         "valu_busy_measured": prof.get("valu_busy"), "counters_source": prof.get("source"),
         "wave_steps_per_s": wave_steps_per_s, "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
+        "streams": streams, "walk_busy_ms_per_step": walk_ms_step, "walk_sum_ms_per_step": walk_sum_step,
         "traffic": traffic,
         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per walker x "
                         "this shard's walkers; profiles/)",
-        "hbm": {"achieved": (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": (traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
+        "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None},
         "algorithmic_hbm": {
             "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
             "bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch, "bytes_per_launch": alg_bytes_per_launch,

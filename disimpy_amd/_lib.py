@@ -18,7 +18,7 @@ SYMBOLS = (
     "dsim_run_free", "dsim_run_sphere", "dsim_run_cylinder", "dsim_run_ellipsoid", "dsim_run_mesh",
     "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
-    "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
+    "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
     "dsim_write_traj", "dsim_write_traj_line",
 )  # fmt: skip
 
@@ -95,6 +95,7 @@ def load():
     lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
     lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
     lib.dsim_last_walk_ms.argtypes = [_h, _f64p, _i32p]
+    lib.dsim_last_walk_busy_ms.argtypes = [_h, _f64p, _i32p]
     lib.dsim_set_tuning.argtypes = [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.dsim_set_recording.argtypes = [_h, C.c_int32]
     lib.dsim_get_recorded.argtypes = [_h, C.c_int32, C.c_int32, _f64p]
@@ -291,6 +292,13 @@ class Sim:
         ms, nl = C.c_double(0), C.c_int32(0)
         check(self._lib.dsim_last_walk_ms(self._h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    def last_walk_busy_ms(self):
+        """(ms during which at least one walk kernel was running, streams used) of the last run_* call: a large
+        mesh shard is run as two halves on two streams, whose launches overlap."""
+        ms, ns = C.c_double(0), C.c_int32(0)
+        check(self._lib.dsim_last_walk_busy_ms(self._h, C.byref(ms), C.byref(ns)))
+        return ms.value, ns.value
 
     # outputs ------------------------------------------------------------------
     def signal(self):

@@ -248,6 +248,15 @@ struct dsim_sim {
   /* per-walker clocks of the cooperative mesh kernel (run_impl, own_clock) */
   int32_t *tcur[2] = {nullptr, nullptr};
   unsigned long long *progress = nullptr; /* {walkers not yet at t_end, time steps they still have to take, most left} */
+  /* second walker group of a grouped run (run_own_clock): its own stream, sort scratch and counters */
+  hipStream_t grp_stream = nullptr;
+  hipEvent_t grp_ev = nullptr;
+  void *grp_sort_tmp = nullptr;
+  size_t grp_sort_tmp_bytes = 0;
+  unsigned long long *grp_counters = nullptr; /* [4]: progress (3) + clear count */
+  std::vector<hipEvent_t> grp_walk_ev;
+  int grp_walk_ev_used = 0;
+  double last_walk_busy_ms = 0; /* time during which at least one walk kernel was running */
   double last_clear_frac = 0;
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
   bool sort_ready = false;
@@ -286,10 +295,6 @@ static void free_mesh(DevMesh &m) {
 static int ensure_staging(dsim_sim *h, size_t bytes) {
   if (h->staging_bytes >= bytes) return DSIM_OK;
   if (h->staging) (void)hipFree(h->staging);
-  if (h->clear_count) (void)hipFree(h->clear_count);
-  for (int b = 0; b < 2; b++)
-    if (h->tcur[b]) (void)hipFree(h->tcur[b]);
-  if (h->progress) (void)hipFree(h->progress);
   h->staging = nullptr;
   h->staging_bytes = 0;
   HIP_TRY(hipMalloc(&h->staging, bytes));
@@ -314,6 +319,15 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->nexc_partial) (void)hipFree(h->nexc_partial);
   if (h->sig_out) (void)hipFree(h->sig_out);
   if (h->staging) (void)hipFree(h->staging);
+  if (h->clear_count) (void)hipFree(h->clear_count);
+  for (int b = 0; b < 2; b++)
+    if (h->tcur[b]) (void)hipFree(h->tcur[b]);
+  if (h->progress) (void)hipFree(h->progress);
+  if (h->grp_sort_tmp) (void)hipFree(h->grp_sort_tmp);
+  if (h->grp_counters) (void)hipFree(h->grp_counters);
+  for (hipEvent_t e : h->grp_walk_ev) (void)hipEventDestroy(e);
+  if (h->grp_ev) (void)hipEventDestroy(h->grp_ev);
+  if (h->grp_stream) (void)hipStreamDestroy(h->grp_stream);
   if (h->phase_alt) (void)hipFree(h->phase_alt);
   if (h->traj) (void)hipFree(h->traj);
   if (h->exc_alt) (void)hipFree(h->exc_alt);
@@ -1220,6 +1234,255 @@ __global__ void clear_count_kernel(const double *x, const double *y, const doubl
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 
+/* ---- mesh runs with per-walker clocks (cooperative kernel, re-sorted walkers, nothing recorded) ---------------
+ * A launch is a budget of passes per wavefront, not a range of time steps: a lane that needs fewer passes than its
+ * neighbours (no reflections) simply gets further instead of idling until the slowest lane of its wavefront has
+ * finished the range.  tcur[i] holds the next time step of walker i between launches; walkers that have reached
+ * t_end are sorted to the end, where their wavefronts exit at once.  The call returns when every walker is at
+ * t_end, so nothing outside sees the clocks.
+ *
+ * Walker groups.  All wavefronts of a launch get the same budget, so they finish together, round after round of
+ * the 4096 wavefront slots of the GPU - and the last round is as full as the walker count happens to make it
+ * (1.25e6 walkers = 4.77 rounds: 5 % of the slots idle), after which the re-sort and the read-back of the
+ * progress counters run on an otherwise empty device.  With M = 1 and enough walkers the shard is therefore cut
+ * into two halves that are sorted and launched independently of each other on two streams (walkers do not
+ * interact; every array of the handle is simply addressed at an offset): while one half drains, sorts and
+ * reports, the other half's launch has the machine.  Same-box A/B on C5b: +6 % at 1.25e6 walkers, +1 % at 1e7.
+ * The host drives both halves from this one thread: issue A, issue B, then wait for whichever was issued first,
+ * read its counters and issue its next launch. */
+struct WalkGroup {
+  dsim_sim v; /* the handle's arrays narrowed to this group's walkers (a view: owns nothing) */
+  int64_t off = 0;
+  std::vector<hipEvent_t> *ev = nullptr;
+  int *ev_used = nullptr;
+  unsigned long long *progress = nullptr, *clear_count = nullptr;
+  long long unfinished = 0, steps_left = 0, max_left = 0;
+  double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
+  int budget = INT_MAX, launches_left = 1 << 20;
+  bool permuted = false, inflight = false;
+};
+
+static int walker_groups(const dsim_sim *h) {
+  int want = 0; /* development override: DSIM_GROUPS=1|2 */
+  if (const char *e = getenv("DSIM_GROUPS")) want = atoi(e);
+  if (h->M != 1) return 1; /* the phase matrix of a view would need a row stride */
+  if (want == 1) return 1;
+  if (want == 2) return h->n >= 8192 ? 2 : 1;
+  return h->n >= (1 << 18) ? 2 : 1;
+}
+
+static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bool clear_auto, int mb, int block, size_t lds, int resort,
+                         int32_t t_begin, int32_t t_end) {
+  const int n_groups = walker_groups(h);
+  if (!h->clear_count) HIP_TRY(hipMalloc(&h->clear_count, sizeof(unsigned long long)));
+  WalkGroup grp[2];
+  const int64_t cut = n_groups == 2 ? ((h->n / 2 + 255) & ~(int64_t)255) : h->n;
+  for (int k = 0; k < n_groups; k++) {
+    WalkGroup &g = grp[k];
+    g.v = *h;
+    g.off = k == 0 ? 0 : cut;
+    g.v.n = k == 0 ? cut : h->n - cut;
+    g.ev = k == 0 ? &h->walk_ev : &h->grp_walk_ev;
+    g.ev_used = k == 0 ? &h->walk_ev_used : &h->grp_walk_ev_used;
+    g.progress = h->progress;
+    g.clear_count = h->clear_count;
+    if (k == 1) {
+      if (!h->grp_stream) HIP_TRY(hipStreamCreateWithFlags(&h->grp_stream, hipStreamNonBlocking));
+      if (!h->grp_ev) HIP_TRY(hipEventCreate(&h->grp_ev));
+      if (!h->grp_counters) HIP_TRY(hipMalloc(&h->grp_counters, 4 * sizeof(unsigned long long)));
+      size_t bytes = 0;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)g.v.n, 0, 31, h->grp_stream));
+      if (bytes > h->grp_sort_tmp_bytes) {
+        if (h->grp_sort_tmp) HIP_TRY(hipFree(h->grp_sort_tmp));
+        h->grp_sort_tmp = nullptr;
+        h->grp_sort_tmp_bytes = 0;
+        HIP_TRY(hipMalloc(&h->grp_sort_tmp, bytes));
+        h->grp_sort_tmp_bytes = bytes;
+      }
+      g.v.stream = h->grp_stream;
+      g.v.sort_tmp = h->grp_sort_tmp;
+      g.v.sort_tmp_bytes = h->grp_sort_tmp_bytes;
+      g.progress = h->grp_counters;
+      g.clear_count = h->grp_counters + 3;
+      for (int b = 0; b < 2; b++) {
+        g.v.x[b] += g.off, g.v.y[b] += g.off, g.v.z[b] += g.off, g.v.s0[b] += g.off, g.v.s1[b] += g.off;
+        g.v.tcur[b] += g.off, g.v.orig[b] += g.off, g.v.keys[b] += g.off;
+      }
+      g.v.phase += g.off, g.v.phase_alt += g.off, g.v.exc += g.off, g.v.exc_alt += g.off, g.v.perm += g.off;
+      /* iota is NOT moved: a group numbers its walkers from 0 */
+    }
+    g.unfinished = g.v.n;
+    g.steps_left = (long long)g.v.n * (t_end - t_begin);
+    g.max_left = t_end - t_begin;
+  }
+  h->grp_walk_ev_used = 0;
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  if (n_groups == 2) HIP_TRY(hipStreamWaitEvent(h->grp_stream, h->ev0, 0)); /* after whatever the handle's stream still holds */
+  for (int k = 0; k < n_groups; k++) {
+    fill_i32_kernel<<<grid_for(grp[k].v.n, 256), 256, 0, grp[k].v.stream>>>(grp[k].v.tcur[grp[k].v.cur], grp[k].v.n, t_begin);
+    HIP_TRY(hipGetLastError());
+  }
+  /* one launch of a group: re-sort, (clearance map decision,) walk kernel, progress counters */
+  auto issue = [&](WalkGroup &g) -> int {
+    dsim_sim *v = &g.v;
+    if (--g.launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
+    /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
+     * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
+    g.budget = g.max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(g.passes_per_step * resort) + 2;
+    int rc = resort_walkers(v, !g.permuted, true, t_end, g.budget == INT_MAX && g.max_left < t_end - t_begin);
+    if (rc) return rc;
+    g.permuted = true;
+    WalkParams q = p;
+    if (clear_auto) {
+      /* The map pays when whole wavefronts are clear (they then run at the cost of free diffusion); with a
+       * minority of clear walkers scattered over the wavefronts its two look-ups per step cost more than the
+       * skipped passes save (neuron, walkers inside: 21 % clear, -1.5 %).  Decide per launch from the share
+       * of walkers that are clear right now - results do not depend on the choice. */
+      HIP_TRY(hipMemsetAsync(g.clear_count, 0, sizeof(unsigned long long), v->stream));
+      clear_count_kernel<<<grid_for(v->n, 256), 256, 0, v->stream>>>(v->x[v->cur], v->y[v->cur], v->z[v->cur], v->n, clear_map, g.clear_count);
+      HIP_TRY(hipGetLastError());
+      unsigned long long cnt = 0;
+      HIP_TRY(hipMemcpyAsync(&cnt, g.clear_count, sizeof(cnt), hipMemcpyDeviceToHost, v->stream));
+      HIP_TRY(hipStreamSynchronize(v->stream));
+      h->last_clear_frac = (double)cnt / (double)v->n;
+      q.mesh.clear_idx = h->last_clear_frac >= 0.4 ? clear_map.clear_idx : nullptr;
+    }
+    const int c = v->cur;
+    q.n = v->n;
+    q.x_in = q.x_out = v->x[c];
+    q.y_in = q.y_out = v->y[c];
+    q.z_in = q.z_out = v->z[c];
+    q.s0_in = q.s0_out = v->s0[c];
+    q.s1_in = q.s1_out = v->s1[c];
+    q.phase = v->phase;
+    q.exc = v->exc;
+    q.t_begin = t_begin;
+    q.t_end = t_end;
+    q.traj = nullptr;
+    q.tcur = v->tcur[c];
+    q.iter_budget = g.budget;
+    q.m0 = 0;
+    q.mc = std::min(mb, h->M);
+    q.write_state = true;
+    if (*g.ev_used + 2 > (int)g.ev->size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      HIP_TRY(hipEventCreate(&a));
+      g.ev->push_back(a);
+      HIP_TRY(hipEventCreate(&b));
+      g.ev->push_back(b);
+    }
+    const int grid = (grid_for(v->n, block) + 255) & ~255; /* XCD-aware group mapping in the kernel */
+    HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used], v->stream));
+    hipError_t e = launch_mb<GEOM_MESH>(mb, q, grid, block, lds, v->stream, h->grad_src, 1);
+    if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used + 1], v->stream));
+    *g.ev_used += 2;
+    h->last_launches++;
+    HIP_TRY(hipMemsetAsync(g.progress, 0, 3 * sizeof(unsigned long long), v->stream));
+    progress_kernel<<<grid_for(v->n, 256), 256, 0, v->stream>>>(v->tcur[c], v->n, t_end, g.progress);
+    HIP_TRY(hipGetLastError());
+    g.inflight = true;
+    return DSIM_OK;
+  };
+  /* wait for the group's launch and read how far its walkers got */
+  auto collect = [&](WalkGroup &g) -> int {
+    unsigned long long pr[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(pr, g.progress, sizeof(pr), hipMemcpyDeviceToHost, g.v.stream));
+    HIP_TRY(hipStreamSynchronize(g.v.stream));
+    g.inflight = false;
+    const long long done = g.steps_left - (long long)pr[1];
+    if (done > 0 && g.budget != INT_MAX) {
+      const double measured = (double)g.budget * (double)g.unfinished / (double)done; /* an upper estimate: finished lanes idle */
+      g.passes_per_step = std::min(4.0, std::max(1.0, 0.5 * g.passes_per_step + 0.5 * measured));
+    }
+    g.unfinished = (long long)pr[0];
+    g.steps_left = (long long)pr[1];
+    g.max_left = (long long)pr[2];
+    return DSIM_OK;
+  };
+  auto drive = [&]() -> int {
+    for (int k = 0; k < n_groups; k++) {
+      int rc = issue(grp[k]);
+      if (rc) return rc;
+    }
+    for (bool any = true; any;) {
+      any = false;
+      for (int k = 0; k < n_groups; k++) {
+        WalkGroup &g = grp[k];
+        if (!g.inflight) continue;
+        int rc = collect(g);
+        if (rc) return rc;
+        if (g.unfinished > 0) {
+          rc = issue(g);
+          if (rc) return rc;
+          any = true;
+        }
+      }
+    }
+    return DSIM_OK;
+  };
+  const int loop_rc = drive();
+  /* whatever happened, the walker order is put back before anything is reported (getters must never see Morton
+   * order), and the halves end up in the same buffers */
+  const std::string keep = g_err;
+  int rc = DSIM_OK;
+  for (int k = 0; k < n_groups && !rc; k++)
+    if (grp[k].permuted) rc = restore_walker_order(&grp[k].v);
+  if (!rc) {
+    h->cur = grp[0].v.cur;
+    h->orig_cur = grp[0].v.orig_cur;
+    h->phase = grp[0].v.phase, h->phase_alt = grp[0].v.phase_alt;
+    h->exc = grp[0].v.exc, h->exc_alt = grp[0].v.exc_alt;
+    if (n_groups == 2) {
+      const dsim_sim &v = grp[1].v;
+      const int64_t off = grp[1].off, cnt = v.n;
+      auto move = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        return dst == src ? hipSuccess : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, v.stream);
+      };
+      const int hc = h->cur, vc = v.cur;
+      hipError_t e = move(h->x[hc] + off, v.x[vc], cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->y[hc] + off, v.y[vc], cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->z[hc] + off, v.z[vc], cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->s0[hc] + off, v.s0[vc], cnt * sizeof(uint64_t));
+      if (e == hipSuccess) e = move(h->s1[hc] + off, v.s1[vc], cnt * sizeof(uint64_t));
+      if (e == hipSuccess) e = move(h->phase + off, v.phase, cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->exc + off, v.exc, cnt);
+      if (e != hipSuccess) rc = fail(DSIM_ERR_HIP, "merging the walker groups failed: %s", hipGetErrorString(e));
+    }
+  }
+  for (int k = 0; k < n_groups; k++) (void)hipStreamSynchronize(grp[k].v.stream);
+  if (loop_rc) {
+    g_err = keep;
+    return loop_rc;
+  }
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->last_ms = ms;
+  /* walk-kernel time: the sum over the launches (what a kernel trace adds up) and the time during which at
+   * least one of them was running (what the throughput of the kernel follows from when two groups overlap) */
+  std::vector<std::pair<float, float>> spans;
+  for (int k = 0; k < n_groups; k++)
+    for (int i = 0; i + 1 < *grp[k].ev_used; i += 2) {
+      float a = 0, b = 0;
+      HIP_TRY(hipEventElapsedTime(&a, h->ev0, (*grp[k].ev)[i]));
+      HIP_TRY(hipEventElapsedTime(&b, h->ev0, (*grp[k].ev)[i + 1]));
+      h->last_walk_ms += b - a;
+      spans.emplace_back(a, b);
+    }
+  std::sort(spans.begin(), spans.end());
+  float busy = 0, hi = -1e30f;
+  for (auto &sp : spans) {
+    if (sp.second <= hi) continue;
+    busy += sp.second - std::max(sp.first, hi);
+    hi = sp.second;
+  }
+  h->last_walk_busy_ms = busy;
+  return DSIM_OK;
+}
+
 static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_t t_end) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (t_begin < 0 || t_end > h->T || t_begin > t_end) return fail(DSIM_ERR_INVALID, "time range [%d, %d) outside [0, %d)", t_begin, t_end, h->T);
@@ -1227,7 +1490,9 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   h->last_ms = 0;
   h->last_launches = 0;
   h->last_walk_ms = 0;
+  h->last_walk_busy_ms = 0;
   h->walk_ev_used = 0;
+  h->grp_walk_ev_used = 0;
   if (t_begin == t_end) return DSIM_OK;
   const int mb_all = pick_mb(h->M, h->meas_per_pass);
   const int passes_all = (h->M + mb_all - 1) / mb_all;
@@ -1328,40 +1593,24 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   }
   /* clearance map: mesh_traversal 2 = decide per launch, 4 = always, 3 (and the per-lane traversal) = never */
   const MeshDev clear_map = p.mesh;
-  const bool clear_forced = h->mesh_traversal == 4;
   if (geom != GEOM_MESH || !coop || h->mesh_traversal == 3) p.mesh.clear_idx = nullptr;
+  const bool clear_auto = p.mesh.clear_idx != nullptr && h->mesh_traversal != 4;
+  /* mesh, cooperative kernel, re-sorted walkers, nothing recorded: per-walker clocks (run_own_clock) */
+  if (coop4 && resort > 0 && !record && passes == 1 && h->mesh_traversal != 5)
+    return run_own_clock(h, p, clear_map, clear_auto, mb, block, lds, resort, t_begin, t_end);
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   bool permuted = false;
   /* the time loop; any failure inside leaves through `return`, and the walker order is put back
    * below before the error is reported (getters must never see Morton order) */
-  /* Per-walker clocks (cooperative kernel, re-sorted walkers, nothing recorded): a launch is a budget of passes per
-   * wavefront, not a range of time steps - a lane that needs fewer passes than its neighbours (no reflections) simply
-   * gets further instead of idling until the slowest lane of its wavefront has finished the range.  tcur[i] holds the
-   * next time step of walker i between launches; walkers that have reached t_end are sorted to the end, where their
-   * wavefronts exit at once.  The call returns when every walker is at t_end, so nothing outside sees the clocks. */
-  const bool own_clock = coop4 && resort > 0 && !record && passes == 1 && h->mesh_traversal != 5;
-  long long unfinished = h->n, steps_left = (long long)h->n * (t_end - t_begin), max_left = t_end - t_begin;
-  double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
-  int budget = INT_MAX, launches_left = 1 << 20;
-  if (own_clock) {
-    fill_i32_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->tcur[h->cur], h->n, t_begin);
-    HIP_TRY(hipGetLastError());
-  }
   auto time_loop = [&]() -> int {
-  for (int ca = t_begin; own_clock ? unfinished > 0 : ca < t_end;) {
-    const int cb = own_clock ? t_end : (resort > 0 ? std::min(t_end, ca + resort) : t_end);
-    if (own_clock) {
-      if (--launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
-      /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
-       * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
-      budget = max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(passes_per_step * resort) + 2;
-    }
+  for (int ca = t_begin; ca < t_end;) {
+    const int cb = resort > 0 ? std::min(t_end, ca + resort) : t_end;
     if (resort > 0) {
-      int rc = resort_walkers(h, !permuted, own_clock, t_end, own_clock && budget == INT_MAX && max_left < t_end - t_begin);
+      int rc = resort_walkers(h, !permuted);
       if (rc) return rc;
       permuted = true;
     }
-    if (clear_map.clear_idx && !clear_forced) {
+    if (clear_auto) {
       /* The map pays when whole wavefronts are clear (they then run at the cost of free diffusion); with a
        * minority of clear walkers scattered over the wavefronts its two look-ups per step cost more than the
        * skipped passes save (neuron, walkers inside: 21 % clear, -1.5 %).  Decide per launch from the share
@@ -1391,11 +1640,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     p.s1_out = h->s1[dst];
     p.phase = h->phase;
     p.exc = h->exc;
-    p.t_begin = own_clock ? t_begin : ta;
+    p.t_begin = ta;
     p.t_end = tb;
     p.traj = record ? h->traj : nullptr;
-    p.tcur = own_clock ? h->tcur[h->cur] : nullptr;
-    p.iter_budget = budget;
+    p.tcur = nullptr;
+    p.iter_budget = INT_MAX;
     for (int pass = 0; pass < passes; pass++) {
       p.m0 = pass * mb;
       p.mc = split_phase ? 0 : std::min(mb, h->M - p.m0);
@@ -1445,23 +1694,6 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     }
     ta = tb;
    }
-    if (own_clock) {
-      HIP_TRY(hipMemsetAsync(h->progress, 0, 3 * sizeof(unsigned long long), h->stream));
-      progress_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(h->tcur[h->cur], h->n, t_end, h->progress);
-      HIP_TRY(hipGetLastError());
-      unsigned long long pr[3] = {0, 0, 0};
-      HIP_TRY(hipMemcpyAsync(pr, h->progress, sizeof(pr), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      const long long done = steps_left - (long long)pr[1];
-      if (done > 0 && budget != INT_MAX) {
-        const double measured = (double)budget * (double)unfinished / (double)done; /* an upper estimate: finished lanes idle */
-        passes_per_step = std::min(4.0, std::max(1.0, 0.5 * passes_per_step + 0.5 * measured));
-      }
-      unfinished = (long long)pr[0];
-      steps_left = (long long)pr[1];
-      max_left = (long long)pr[2];
-      continue; /* ca stays: the next launch again covers [t_begin, t_end) with the walkers' own clocks */
-    }
     ca = cb;
   }
   return DSIM_OK;
@@ -1492,6 +1724,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     HIP_TRY(hipEventElapsedTime(&w, h->walk_ev[i], h->walk_ev[i + 1]));
     h->last_walk_ms += w;
   }
+  h->last_walk_busy_ms = h->last_walk_ms; /* one stream: the launches do not overlap */
   return DSIM_OK;
 }
 
@@ -1758,7 +1991,14 @@ extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) 
 extern "C" int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_walk_ms;
-  if (n_launches) *n_launches = h->walk_ev_used / 2;
+  if (n_launches) *n_launches = (h->walk_ev_used + h->grp_walk_ev_used) / 2;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_last_walk_busy_ms(dsim_handle h, double *ms, int32_t *n_streams) {
+  if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (ms) *ms = h->last_walk_busy_ms;
+  if (n_streams) *n_streams = h->grp_walk_ev_used > 0 ? 2 : 1;
   return DSIM_OK;
 }
 

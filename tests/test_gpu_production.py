@@ -40,7 +40,7 @@ def _oracle_mesh(o, ma, n, g, dt, step_l, pos0, seed, perm_prob=0.0, want_traj=F
                 traj=traj)
 
 
-def test_neuron_production_shape_resorted_launches(lib, oracle_exact):
+def test_neuron_production_shape_resorted_launches(lib, oracle_exact, monkeypatch):
     """Neuron (29 688 triangles, 50^3 index, walkers inside), the C5 step length, 8192 walkers x
     2200 steps: automatic re-sort interval (1024 steps => 3 sorts, 3 launches of
     walk_kernel_coop4, XCD-aware group mapping, walkers advancing at their own pace)."""
@@ -57,8 +57,12 @@ def test_neuron_production_shape_resorted_launches(lib, oracle_exact):
     kw = dict(max_iter=1000, epsilon=1e-13)
     # default tuning = what bench.py runs: per-walker clocks (a launch is a budget of passes per wavefront; walkers
     # reach step 2200 in different launches); mesh_traversal 5 = every launch covers the same steps for all walkers;
-    # and the default again in two calls (all walkers are synchronised at every call boundary)
-    for tuning, chunks in ((None, [0, T]), (dict(mesh_traversal=5), [0, T]), (None, [0, 1500, T])):
+    # and the default again in two calls (all walkers are synchronised at every call boundary); then the same with
+    # the shard cut into two halves that are sorted and launched independently on two streams (what the library
+    # does by itself from 2^18 walkers on; DSIM_GROUPS=2 asks for it here)
+    for tuning, chunks, groups in ((None, [0, T], 1), (dict(mesh_traversal=5), [0, T], 1), (None, [0, 1500, T], 1),
+                                   (None, [0, T], 2), (None, [0, 700, T], 2)):
+        monkeypatch.setenv("DSIM_GROUPS", str(groups))
         with lib.Sim(n, g, dt, step_l) as sim:
             if tuning:
                 sim.set_tuning(**tuning)
@@ -69,11 +73,42 @@ def test_neuron_production_shape_resorted_launches(lib, oracle_exact):
                 sim.run_mesh(1000, 1e-13, 0.0, t0, t1)
             if len(chunks) == 2:
                 assert sim.last_run_ms()[1] >= 3 and sim.last_walk_ms()[1] >= 3  # >= 2 re-sort intervals, >= 2 launches
+            busy, streams = sim.last_walk_busy_ms()
+            assert streams == (2 if groups == 2 and not tuning else 1)
+            assert 0 < busy <= sim.last_walk_ms()[0] * 1.001
             c, s, _ = sim.signal()
             gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
         _assert_identical(gpu, ref)
     assert (gpu["pos"].max(axis=0) < sub.voxel_size).all() and (gpu["pos"].min(axis=0) > 0).all()
     del kw
+
+
+def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_exact, monkeypatch):
+    """Two independently sorted halves (DSIM_GROUPS=2) of an odd number of walkers - 9001 = 4608 + 4393 - in the
+    closed cylinder mesh with permeable walls (crossings draw an extra uniform), two measurements refused (the
+    phase matrix of a half would need a row stride: M = 2 runs as one group), M = 1 accepted."""
+    from disimpy_amd import substrates
+
+    m = golden("cylinder_mesh_closed.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, n_sv=np.array([10, 10, 10]), perm_prob=0.35, quiet=True)
+    n, T, dt = 9001, 700, 1e-3
+    step_l = float(np.sqrt(6 * D * dt))
+    pos0 = np.random.RandomState(5).random_sample((n, 3)) * sub.voxel_size
+    ma = _mesh_arrays(sub)
+    monkeypatch.setenv("DSIM_GROUPS", "2")
+    for M in (1, 2):
+        g = _random_gradient(M, T)
+        ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 11, perm_prob=0.35)
+        with lib.Sim(n, g, dt, step_l) as sim:
+            sim.set_tuning(resort_steps=128)
+            sim.rng_init_device(11)
+            sim.set_positions(pos0)
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+            sim.run_mesh(1000, 1e-13, 0.35, 0, T)
+            assert sim.last_walk_busy_ms()[1] == (2 if M == 1 else 1)
+            c, s, _ = sim.signal()
+            gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
+        _assert_identical(gpu, ref)
 
 
 def test_c4_packed_cylinders_bit_identical(lib, oracle_exact):
