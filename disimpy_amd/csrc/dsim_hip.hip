@@ -1322,6 +1322,8 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     fill_i32_kernel<<<grid_for(grp[k].v.n, 256), 256, 0, grp[k].v.stream>>>(grp[k].v.tcur[grp[k].v.cur], grp[k].v.n, t_begin);
     HIP_TRY(hipGetLastError());
   }
+  bool stagger = n_groups == 2;
+  if (const char *e = getenv("DSIM_STAGGER")) stagger = stagger && atoi(e) != 0; /* development override */
   /* one launch of a group: re-sort, (clearance map decision,) walk kernel, progress counters */
   auto issue = [&](WalkGroup &g) -> int {
     dsim_sim *v = &g.v;
@@ -1329,6 +1331,9 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
      * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
     g.budget = g.max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(g.passes_per_step * resort) + 2;
+    /* the second group's first launch is half as long: from then on one group is in the middle of a launch whenever
+     * the other one drains (equal halves with equal budgets would march in step and drain together) */
+    if (stagger && &g == &grp[1] && !g.permuted && g.budget != INT_MAX) g.budget = (g.budget + 1) / 2;
     int rc = resort_walkers(v, !g.permuted, true, t_end, g.budget == INT_MAX && g.max_left < t_end - t_begin);
     if (rc) return rc;
     g.permuted = true;

@@ -78,7 +78,9 @@ def main():
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         raw[name] = summarise(out, args.match)
         if line:
-            raw[name]["bench"] = {k: json.loads(line[-1]).get(k) for k in ("value", "config", "walk_kernel_spin_steps_per_s")}
+            d = json.loads(line[-1])
+            raw[name]["bench"] = {k: d.get(k) for k in ("value", "config", "walk_kernel_spin_steps_per_s")}
+            raw[name]["bench"]["streams"] = (d.get("roofline") or {}).get("streams", 1)
     dst = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (args.tag, args.workload))
     json.dump(raw, open(dst, "w"), indent=1)
     T = (raw.get("sq", {}).get("bench", {}).get("config") or {}).get("time_steps") or 10000
@@ -104,8 +106,11 @@ def main():
         wr = raw["write"]["counters"]["WRITE_SIZE"] * 1024
         entry["hbm_read_bytes_per_launch"] = rd / nl
         entry["hbm_write_bytes_per_launch"] = wr / nl
-        entry["hbm_bytes_per_walker_launch"] = (rd + wr) / nl / args.walkers
+        # a large mesh shard runs as two halves on two streams: a launch then covers walkers / streams walkers
+        streams = (raw["fetch"].get("bench") or {}).get("streams") or 1
+        entry["hbm_bytes_per_walker_launch"] = (rd + wr) / nl / (args.walkers / streams)
         entry["launches"] = nl
+        entry["streams"] = streams
     kc = os.path.join(ROOT, "profiles", "kernel_counters.json")
     allc = json.load(open(kc)) if os.path.exists(kc) else {}
     allc[args.workload] = entry
