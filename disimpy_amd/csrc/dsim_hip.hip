@@ -1247,7 +1247,9 @@ __global__ void clear_count_kernel(const double *x, const double *y, const doubl
  * progress counters run on an otherwise empty device.  With M = 1 and enough walkers the shard is therefore cut
  * into two halves that are sorted and launched independently of each other on two streams (walkers do not
  * interact; every array of the handle is simply addressed at an offset): while one half drains, sorts and
- * reports, the other half's launch has the machine.  Same-box A/B on C5b: +6 % at 1.25e6 walkers, +1 % at 1e7.
+ * reports, the other half's launch has the machine.  Same-box A/B on C5b: +4.5 % at 1.25e6 walkers, +0.6 % at 1e7
+ * (C4, 1e6 walkers: +8 %).  The blocks of the launch that was issued first are dispatched first, so the halves
+ * take turns by themselves; shortening the second half's first launch to put them half a launch apart cost 1-3 %.
  * The host drives both halves from this one thread: issue A, issue B, then wait for whichever was issued first,
  * read its counters and issue its next launch. */
 struct WalkGroup {
@@ -1322,8 +1324,6 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     fill_i32_kernel<<<grid_for(grp[k].v.n, 256), 256, 0, grp[k].v.stream>>>(grp[k].v.tcur[grp[k].v.cur], grp[k].v.n, t_begin);
     HIP_TRY(hipGetLastError());
   }
-  bool stagger = n_groups == 2;
-  if (const char *e = getenv("DSIM_STAGGER")) stagger = stagger && atoi(e) != 0; /* development override */
   /* one launch of a group: re-sort, (clearance map decision,) walk kernel, progress counters */
   auto issue = [&](WalkGroup &g) -> int {
     dsim_sim *v = &g.v;
@@ -1331,9 +1331,6 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
      * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
     g.budget = g.max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(g.passes_per_step * resort) + 2;
-    /* the second group's first launch is half as long: from then on one group is in the middle of a launch whenever
-     * the other one drains (equal halves with equal budgets would march in step and drain together) */
-    if (stagger && &g == &grp[1] && !g.permuted && g.budget != INT_MAX) g.budget = (g.budget + 1) / 2;
     int rc = resort_walkers(v, !g.permuted, true, t_end, g.budget == INT_MAX && g.max_left < t_end - t_begin);
     if (rc) return rc;
     g.permuted = true;
