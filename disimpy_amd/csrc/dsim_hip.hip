@@ -1562,6 +1562,17 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
        * in neighbouring subvoxels for several hundred steps, and every launch boundary idles the
        * lanes that are ahead of their neighbours: 512..1024 steps, longer where walkers move slowly */
       resort = (int)std::min(1024.0, std::max(512.0, 8.0 * r * r));
+      /* A launch that is only a few rounds of the GPU's 4096 wavefront slots long pays for long workgroups twice:
+       * its last round is partly empty for a whole workgroup duration, and the short kernels between two launches
+       * of a group (keys, radix sort, gathers, counters: ~30 dispatches) each wait for a workgroup of the other
+       * group's launch to end before they find a free slot.  Shorter launches shorten both waits; with many rounds
+       * per launch the sorts themselves weigh more.  Measured on C5b with two walker groups (resort 1024 -> 256):
+       * +3.6 % at 1.25e6 walkers, +0.9 % on C4 at 1e6; at 1e7 walkers 1024 -> 512 costs 0.8 %. */
+      const double rounds = (double)h->n / (double)walker_groups(h) / 64.0 / 4096.0;
+      if (coop4 && rounds < 4.0)
+        resort = std::min(resort, 256);
+      else if (coop4 && rounds < 10.0)
+        resort = std::min(resort, 512);
     }
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
