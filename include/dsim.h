@@ -213,7 +213,9 @@ int dsim_write_traj_line(const char *path, const double *positions_aos, int64_t 
 /* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
  * LDS gradient tile, measurements held in registers per pass, and - for mesh
  * substrates - the number of time steps between spatial re-sorts of the walker
- * slots (0 = automatic, negative = never), and where the kernels read the
+ * slots (0 = automatic: 512..1024 from the subvoxel size and the step length,
+ * shortened to 512 / 256 when the shard is so small that a launch is only a
+ * few rounds of the GPU's wavefront slots; negative = never), and where the kernels read the
  * gradient samples from (1 = LDS tiles, 2 = scalar loads), how the mesh index is
  * traversed (1 = per lane, 2 = wavefront-cooperative, using the clearance map -
  * walkers farther than a step from every triangle skip the traversal - in the
