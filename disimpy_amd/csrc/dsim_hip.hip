@@ -245,7 +245,7 @@ struct dsim_sim {
   int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
   int mesh_traversal = 0; /* 0/2 = wavefront-cooperative (clearance map when it pays), 1 = per-lane, 3 = cooperative, never the map, 4 = always */
   unsigned long long *clear_count = nullptr;
-  /* per-walker clocks of the cooperative mesh kernel (run_impl, own_clock) */
+  /* per-walker clocks of the cooperative mesh kernel (run_own_clock) */
   int32_t *tcur[2] = {nullptr, nullptr};
   unsigned long long *progress = nullptr; /* {walkers not yet at t_end, time steps they still have to take, most left} */
   /* second walker group of a grouped run (run_own_clock): its own stream, sort scratch and counters */

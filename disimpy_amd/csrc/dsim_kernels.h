@@ -112,7 +112,7 @@ struct WalkParams {
   double eps, perm_prob;
   MeshDev mesh;
   double *traj; /* walk_kernel_coop4_traj: [t - t_begin][3][n], the positions after every time step of the launch */
-  /* cooperative mesh kernel with per-walker clocks (run_impl, own_clock): tcur[i] = the next time step of walker i
+  /* cooperative mesh kernel with per-walker clocks (dsim_hip.hip, run_own_clock): tcur[i] = the next time step of walker i
    * on entry and on exit; the launch ends when every wavefront has run iter_budget passes (walkers inside a step
    * finish it) or all its walkers have reached t_end.  nullptr: every walker runs [t_begin, t_end). */
   int32_t *tcur;
