@@ -2194,12 +2194,18 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
           const int64_t sv = ((int64_t)x * ny + y) * nz + z;
           const int64_t lo = subvoxel_indices[sv * 2], hi = subvoxel_indices[sv * 2 + 1];
           if (hi <= lo) continue;
+          if (lo < 0 || hi > n_refs) {
+            cleanup();
+            return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: subvoxel %lld lists entries [%lld, %lld) of %lld", (long long)sv, (long long)lo,
+                        (long long)hi, (long long)n_refs);
+          }
           col_ent.push_back(make_int2(x, (int)ent.size()));
           for (int64_t i = lo; i < hi; i++) {
             const int64_t ti = triangle_indices[i];
-            if (i < 0 || i >= n_refs || ti < 0 || ti >= n_faces) {
+            if (ti < 0 || ti >= n_faces) {
               cleanup();
-              return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: subvoxel list entry %lld out of range", (long long)i);
+              return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: list entry %lld names triangle %lld of %lld", (long long)i, (long long)ti,
+                          (long long)n_faces);
             }
             ent.push_back(make_int2((int)ti, last_x[ti]));
             ent_yz.push_back(h_tri_yz[ti]);
