@@ -83,6 +83,32 @@ def test_neuron_production_shape_resorted_launches(lib, oracle_exact, monkeypatc
     del kw
 
 
+def test_neuron_shard_large_enough_for_two_groups_by_default(lib, oracle_exact, monkeypatch):
+    """270 000 walkers x 400 steps in the neuron with nothing forced: from 2^18 walkers on the library cuts the
+    shard into two halves on two streams by itself, and a launch this small re-sorts every 256 steps."""
+    from disimpy_amd import simulations, substrates
+
+    monkeypatch.delenv("DSIM_GROUPS", raising=False)
+    m = golden("neuron_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"].astype(np.int64), True, init_pos="intra", quiet=True)
+    n, T, dt = 270_000, 400, 7e-6
+    step_l = float(np.sqrt(6 * D * dt))
+    g = _random_gradient(1, T)
+    pos0 = simulations._fill_mesh(n, sub, True, 123)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 123)
+    with lib.Sim(n, g, dt, step_l) as sim:
+        sim.rng_init_device(123)
+        sim.set_positions(pos0)
+        sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+        sim.run_mesh(1000, 1e-13, 0.0, 0, T)
+        assert sim.last_walk_busy_ms()[1] == 2
+        assert sim.last_walk_ms()[1] >= 4  # two groups x (a budget worth 256 steps + the rest)
+        c, s, _ = sim.signal()
+        gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
+    _assert_identical(gpu, ref)
+
+
 def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_exact, monkeypatch):
     """Two independently sorted halves (DSIM_GROUPS=2) of an odd number of walkers - 9001 = 4608 + 4393 - in the
     closed cylinder mesh with permeable walls (crossings draw an extra uniform), two measurements refused (the
