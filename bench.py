@@ -444,6 +444,11 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    # stdout carries ONE line, the JSON: whatever the communication libraries print while they start up (RCCL's
+    # version banner, gloo's connection notes) goes to stderr - file descriptor 1 points there until the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -574,8 +579,10 @@ def main(argv=None):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     return 0
 
 
