@@ -250,7 +250,6 @@ struct dsim_sim {
   unsigned long long *progress = nullptr; /* {walkers not yet at t_end, time steps they still have to take, most left} */
   /* second walker group of a grouped run (run_own_clock): its own stream, sort scratch and counters */
   hipStream_t grp_stream = nullptr;
-  hipEvent_t grp_ev = nullptr;
   void *grp_sort_tmp = nullptr;
   size_t grp_sort_tmp_bytes = 0;
   unsigned long long *grp_counters = nullptr; /* [4]: progress (3) + clear count */
@@ -326,7 +325,6 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->grp_sort_tmp) (void)hipFree(h->grp_sort_tmp);
   if (h->grp_counters) (void)hipFree(h->grp_counters);
   for (hipEvent_t e : h->grp_walk_ev) (void)hipEventDestroy(e);
-  if (h->grp_ev) (void)hipEventDestroy(h->grp_ev);
   if (h->grp_stream) (void)hipStreamDestroy(h->grp_stream);
   if (h->phase_alt) (void)hipFree(h->phase_alt);
   if (h->traj) (void)hipFree(h->traj);
@@ -1290,7 +1288,6 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     g.clear_count = h->clear_count;
     if (k == 1) {
       if (!h->grp_stream) HIP_TRY(hipStreamCreateWithFlags(&h->grp_stream, hipStreamNonBlocking));
-      if (!h->grp_ev) HIP_TRY(hipEventCreate(&h->grp_ev));
       if (!h->grp_counters) HIP_TRY(hipMalloc(&h->grp_counters, 4 * sizeof(unsigned long long)));
       size_t bytes = 0;
       HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)g.v.n, 0, 31, h->grp_stream));
