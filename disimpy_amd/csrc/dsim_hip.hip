@@ -220,6 +220,7 @@ struct dsim_sim {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t n = 0, first = 0;
+  int64_t phase_stride = 0; /* row stride of phase / phase_alt: n, also in a view of a sub-range (run_own_clock) */
   int M = 0, T = 0;
   double dt = 0, step_l = 0;
   double *x[2] = {nullptr, nullptr}, *y[2] = {nullptr, nullptr}, *z[2] = {nullptr, nullptr};
@@ -405,6 +406,7 @@ extern "C" int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int6
   dsim_sim *h = new dsim_sim();
   h->device = device;
   h->n = n_walkers;
+  h->phase_stride = n_walkers;
   h->first = first_walker;
   h->M = M;
   h->T = T;
@@ -1193,7 +1195,7 @@ static int resort_walkers(dsim_sim *h, bool first, bool clocks = false, int32_t 
                                                 clocks ? h->tcur[c] : nullptr, h->tcur[o]);
   HIP_TRY(hipGetLastError());
   dim3 pg(g, h->M);
-  gather_rows_kernel<<<pg, 256, 0, h->stream>>>(h->perm, n, h->phase, h->phase_alt);
+  gather_rows_kernel<<<pg, 256, 0, h->stream>>>(h->perm, n, h->phase_stride, h->phase, h->phase_alt);
   HIP_TRY(hipGetLastError());
   std::swap(h->phase, h->phase_alt);
   std::swap(h->exc, h->exc_alt);
@@ -1212,7 +1214,7 @@ static int restore_walker_order(dsim_sim *h) {
                                                  h->s0[o], h->s1[o], h->exc_alt);
   HIP_TRY(hipGetLastError());
   dim3 pg(g, h->M);
-  scatter_rows_kernel<<<pg, 256, 0, h->stream>>>(orig, n, h->phase, h->phase_alt);
+  scatter_rows_kernel<<<pg, 256, 0, h->stream>>>(orig, n, h->phase_stride, h->phase, h->phase_alt);
   HIP_TRY(hipGetLastError());
   std::swap(h->phase, h->phase_alt);
   std::swap(h->exc, h->exc_alt);
@@ -1242,7 +1244,7 @@ __global__ void clear_count_kernel(const double *x, const double *y, const doubl
  * Walker groups.  All wavefronts of a launch get the same budget, so they finish together, round after round of
  * the 4096 wavefront slots of the GPU - and the last round is as full as the walker count happens to make it
  * (1.25e6 walkers = 4.77 rounds: 5 % of the slots idle), after which the re-sort and the read-back of the
- * progress counters run on an otherwise empty device.  With M = 1 and enough walkers the shard is therefore cut
+ * progress counters run on an otherwise empty device.  With enough walkers the shard is therefore cut
  * into two halves that are sorted and launched independently of each other on two streams (walkers do not
  * interact; every array of the handle is simply addressed at an offset): while one half drains, sorts and
  * reports, the other half's launch has the machine.  Same-box A/B on C5b: +4.5 % at 1.25e6 walkers, +0.6 % at 1e7
@@ -1265,7 +1267,6 @@ struct WalkGroup {
 static int walker_groups(const dsim_sim *h) {
   int want = 0; /* development override: DSIM_GROUPS=1|2 */
   if (const char *e = getenv("DSIM_GROUPS")) want = atoi(e);
-  if (h->M != 1) return 1; /* the phase matrix of a view would need a row stride */
   if (want == 1) return 1;
   if (want == 2) return h->n >= 8192 ? 2 : 1;
   return h->n >= (1 << 18) ? 2 : 1;
@@ -1347,7 +1348,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       q.mesh.clear_idx = h->last_clear_frac >= 0.4 ? clear_map.clear_idx : nullptr;
     }
     const int c = v->cur;
-    q.n = v->n;
+    q.n = v->n; /* q.phase_stride stays the handle's */
     q.x_in = q.x_out = v->x[c];
     q.y_in = q.y_out = v->y[c];
     q.z_in = q.z_out = v->z[c];
@@ -1444,7 +1445,8 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       if (e == hipSuccess) e = move(h->z[hc] + off, v.z[vc], cnt * sizeof(double));
       if (e == hipSuccess) e = move(h->s0[hc] + off, v.s0[vc], cnt * sizeof(uint64_t));
       if (e == hipSuccess) e = move(h->s1[hc] + off, v.s1[vc], cnt * sizeof(uint64_t));
-      if (e == hipSuccess) e = move(h->phase + off, v.phase, cnt * sizeof(double));
+      for (int m = 0; m < h->M && e == hipSuccess; m++)
+        e = move(h->phase + (int64_t)m * h->phase_stride + off, v.phase + (int64_t)m * h->phase_stride, cnt * sizeof(double));
       if (e == hipSuccess) e = move(h->exc + off, v.exc, cnt);
       if (e != hipSuccess) rc = fail(DSIM_ERR_HIP, "merging the walker groups failed: %s", hipGetErrorString(e));
     }
@@ -1515,6 +1517,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
    * 32-accumulator kernel is the only one with a recording variant) */
   const int walk_meas = split_phase ? 0 : (record_extra ? std::min(32, h->M) : 0);
   p.n = h->n;
+  p.phase_stride = h->phase_stride;
   p.g4 = h->g4;
   p.M = h->M;
   p.step_l = h->step_l;

@@ -98,7 +98,8 @@ struct WalkParams {
   const uint64_t *s0_in, *s1_in;
   double *x_out, *y_out, *z_out;
   uint64_t *s0_out, *s1_out;
-  double *phase;      /* (M, n) */
+  double *phase;      /* (M, phase_stride): row m starts at phase + m * phase_stride */
+  int64_t phase_stride; /* = n, except when this launch covers a sub-range of the handle's walkers */
   uint8_t *exc;       /* (n,)   */
   const double *g4;   /* [T][M][4] = gx, gy, gz, 0 */
   int M, m0, mc;      /* this pass handles measurements [m0, m0+mc), mc <= MB */
@@ -442,7 +443,7 @@ DSD void walk_body(const WalkParams &p) {
     exc = p.exc[i] != 0;
 #pragma unroll
     for (int m = 0; m < MB; m++)
-      if (m < p.mc) ph[m] = p.phase[(int64_t)(p.m0 + m) * p.n + i];
+      if (m < p.mc) ph[m] = p.phase[(int64_t)(p.m0 + m) * p.phase_stride + i];
   }
 
   for (int t0 = p.t_begin; t0 < p.t_end; t0 += p.tile_steps) {
@@ -583,7 +584,7 @@ DSD void walk_body(const WalkParams &p) {
   if (live) {
 #pragma unroll
     for (int m = 0; m < MB; m++)
-      if (m < p.mc) p.phase[(int64_t)(p.m0 + m) * p.n + i] = ph[m];
+      if (m < p.mc) p.phase[(int64_t)(p.m0 + m) * p.phase_stride + i] = ph[m];
     if (p.write_state) {
       p.x_out[i] = r.x;
       p.y_out[i] = r.y;
@@ -866,9 +867,9 @@ __global__ void gather_state_kernel(const int32_t *perm, int64_t n, const double
   origo[i] = orig[j];
 }
 
-__global__ void gather_rows_kernel(const int32_t *perm, int64_t n, const double *src, double *dst) {
+__global__ void gather_rows_kernel(const int32_t *perm, int64_t n, int64_t stride, const double *src, double *dst) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[(int64_t)blockIdx.y * n + i] = src[(int64_t)blockIdx.y * n + perm[i]];
+  if (i < n) dst[(int64_t)blockIdx.y * stride + i] = src[(int64_t)blockIdx.y * stride + perm[i]];
 }
 
 /* slot i returns to walker index orig[i] */
@@ -886,9 +887,9 @@ __global__ void scatter_state_kernel(const int32_t *orig, int64_t n, const doubl
   exco[j] = exc[i];
 }
 
-__global__ void scatter_rows_kernel(const int32_t *orig, int64_t n, const double *src, double *dst) {
+__global__ void scatter_rows_kernel(const int32_t *orig, int64_t n, int64_t stride, const double *src, double *dst) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[(int64_t)blockIdx.y * n + orig[i]] = src[(int64_t)blockIdx.y * n + i];
+  if (i < n) dst[(int64_t)blockIdx.y * stride + orig[i]] = src[(int64_t)blockIdx.y * stride + i];
 }
 
 /* ---- _cuda_fill_mesh (simulations.py:421-502) ------------------------------------ */

@@ -182,7 +182,7 @@ int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
  * roofline of the dominant kernel is computed from this figure. */
 int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches);
 
-/* Mesh runs with M = 1 and at least 2^18 walkers sort and launch the two halves of the shard independently on
+/* Mesh runs with M <= 2 (the kernel with per-walker clocks) and at least 2^18 walkers sort and launch the two halves of the shard independently on
  * two streams, so that one half's launch fills the wavefront slots the other half leaves idle at the end of its
  * launch and during its re-sort (csrc/dsim_hip.hip, run_own_clock).  The launches of the two halves then overlap
  * and the sum above counts the overlap twice: *ms is the time during which at least one walk kernel was running

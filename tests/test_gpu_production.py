@@ -111,8 +111,8 @@ def test_neuron_shard_large_enough_for_two_groups_by_default(lib, oracle_exact, 
 
 def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_exact, monkeypatch):
     """Two independently sorted halves (DSIM_GROUPS=2) of an odd number of walkers - 9001 = 4608 + 4393 - in the
-    closed cylinder mesh with permeable walls (crossings draw an extra uniform), two measurements refused (the
-    phase matrix of a half would need a row stride: M = 2 runs as one group), M = 1 accepted."""
+    closed cylinder mesh with permeable walls (crossings draw an extra uniform), with one and with two measurements
+    (the rows of the phase matrix of a half keep the handle's row stride)."""
     from disimpy_amd import substrates
 
     m = golden("cylinder_mesh_closed.npz")
@@ -131,7 +131,7 @@ def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_ex
             sim.set_positions(pos0)
             sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
             sim.run_mesh(1000, 1e-13, 0.35, 0, T)
-            assert sim.last_walk_busy_ms()[1] == (2 if M == 1 else 1)
+            assert sim.last_walk_busy_ms()[1] == 2
             c, s, _ = sim.signal()
             gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
         _assert_identical(gpu, ref)
