@@ -27,7 +27,7 @@
  * trips of 64), so the queue sizes bound the LDS footprint, not the work per
  * pass.  The owners' segments (midpoint, half vector and margin: 7 floats, from which the
  * working lane rebuilds the cull box) and rays stay in the owners' registers and
- * are read with ds_bpermute; the kernel then fits 128 VGPRs and 8 KB of LDS per
+ * are read with ds_bpermute; the kernel then fits 128 VGPRs and 7 KB of LDS per
  * wavefront, i.e. 4 wavefronts per SIMD.
  *
  * Which triangles are tested, in fp64, against which ray is unchanged, and the
@@ -48,13 +48,13 @@
 #define COOP_CELLQ_CAP 256
 #define COOP_NO_SHIFT 0x20820u /* tag >> 14 when all three image numbers are 0 (stored + 32, 6 bits each) */
 
-/* Per-wavefront scratch in LDS (8.1 KB).  The owners' cull boxes and rays are NOT here: they
+/* Per-wavefront scratch in LDS (6.9 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
  * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
   unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)      0.5 KB */
   unsigned long long best_key[64];      /* (visit << 32) | list position of the winner                  0.5 KB */
-  double best_n[64][3];                 /* unit normal of the winner's triangle                          1.5 KB */
+  int best_tri[64];                     /* the winner's triangle (its owner fetches the unit normal)    0.25 KB */
   uint2 cellq[COOP_CELLQ_CAP];          /* cell tasks {owner|visit|shifts, index into cell_range  or
                                            0x80000000 | subvoxel (range stored inline)} (1b -> 1c)      2.0 KB */
   /* the next four arrays (3.5 KB) also hold, between stages 1a and 1b, the subvoxel tasks
@@ -338,14 +338,10 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   const bool is_min = valid && d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner];
   if (is_min) atomicMin(&W->best_key[owner], key); /* pass B: among equal d the earliest (visit, position) */
   wave_sync();
-  if (is_min && key == W->best_key[owner]) { /* pass C: the winner publishes its triangle's normal */
-    /* the record is still in the vector L1: publish its unit normal so that the owner does not have to
-     * fetch the triangle before it can reflect */
-    const double *rec = ms.tri + (int64_t)(int)sv.x * DS_TRI_STRIDE;
-    const V3 nn = load_v3(rec + 9);
-    double *bn = W->best_n[owner];
-    bn[0] = nn.x, bn[1] = nn.y, bn[2] = nn.z;
-  }
+  /* pass C: the winner names its triangle.  The owner fetches the precomputed unit normal in stage 4, and only if
+   * the hit lies within the step: most minima of a flush are beaten later or lie beyond the step's end, and a
+   * load here would stall every flush for it */
+  if (is_min && key == W->best_key[owner]) W->best_tri[owner] = (int)sv.x;
   wave_sync();
   T_MARK(W, lane, 6);
 }
@@ -645,9 +641,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     } else {
       const unsigned long long bd = W->best_d[lane];
       if (bd != 0x7ff0000000000000ULL) {
-        const double *bn = W->best_n[lane];
         d = __longlong_as_double((long long)bd);
-        n.x = bn[0], n.y = bn[1], n.z = bn[2];
+        if (d <= step_l) n = load_v3(ms.tri + (int64_t)W->best_tri[lane] * DS_TRI_STRIDE + 9);
       }
     }
     T_MARK(W, lane, 7);
