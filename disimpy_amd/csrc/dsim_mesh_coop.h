@@ -17,9 +17,10 @@
  *             against the OWNER's cull box -> survivor pool;
  *   stage 3   any lane per survivor: fp64 Moller-Trumbore test with the OWNER's
  *             ray, minimum per owner by 64-bit LDS atomics on the bit pattern
- *             of d, ties resolved by a second atomic pass, the winner publishes
- *             its normal;
- *   stage 4   reflection / crossing per walker, then the next pass for the
+ *             of d, ties resolved by a second atomic pass, the winner names its
+ *             triangle;
+ *   stage 4   the owner fetches the unit normal of a hit within the step:
+ *             reflection / crossing per walker, then the next pass for the
  *             walkers that hit something.
  *
  * Stages 1c-3 run in rounds (cells are expanded while the item queue has room,
