@@ -66,6 +66,9 @@ struct CoopWave {
   unsigned surv_tag[COOP_SURV_CAP];     /*   owner|visit|shifts                                                */
   unsigned char overflow[64];           /* some work of this owner did not fit a queue: redo serially          */
   int n_surv, n_svq, pad[2];
+#ifdef DSIM_STATS
+  unsigned filt[64][4]; /* development: (owner, list position) pairs already among the survivors of this pass */
+#endif
 #ifdef DSIM_TIMERS
   unsigned long long tacc[16], tlast;
   unsigned long long tpad;
@@ -393,6 +396,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     W->n_svq = 0;
   }
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
+#ifdef DSIM_STATS
+  W->filt[lane][0] = W->filt[lane][1] = W->filt[lane][2] = W->filt[lane][3] = 0xffffffffu;
+#endif
   W->best_key[lane] = ~0ULL;
   W->overflow[lane] = 0;
   wave_sync();
@@ -597,6 +603,13 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             if (!(alive >> u & 1u)) continue;
+#ifdef DSIM_STATS
+            {
+              const unsigned pos_ = (unsigned)__float_as_int(q2[u].w);
+              const unsigned prev_ = atomicExch(&W->filt[owner][(pos_ ^ (pos_ >> 2)) & 3u], pos_);
+              if (prev_ == pos_) STAT_LANE(7); /* the same list entry of the same owner survived from another cell */
+            }
+#endif
             if (slot < COOP_SURV_CAP) {
               W->surv_tri[slot] = (unsigned)__float_as_int(q2[u].z);
               W->surv_pos[slot] = (unsigned)__float_as_int(q2[u].w);

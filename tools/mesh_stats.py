@@ -13,7 +13,7 @@ from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
 NAMES = ["reflect-loop iterations", "subvoxels visited", "non-empty subvoxels", "non-empty micro-cells",
-         "record batches (4)", "cell tasks (incl. empty cells)", "AABB pass -> fp64 test", "hits (reflections)",
+         "record batches (4)", "cell tasks (incl. empty cells)", "AABB pass -> fp64 test", "duplicate survivors (same owner, same list entry)",
          "coop: cell scanned serially", "coop: survivor overflow redo", "coop: whole iteration serial"]
 
 
