@@ -213,6 +213,7 @@ struct DevMesh {
   double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; /* first and last boundary of every axis */
   bool set = false;
+  bool coop_ok = false; /* fewer than 2^24 triangles and list entries */
 };
 
 struct dsim_sim {
@@ -1027,6 +1028,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     dm.hi[k] = b3[k][n_sv[k]];
   }
   dm.set = true;
+  dm.coop_ok = n_faces < (1 << 24) && n_refs < (1 << 24);
   return DSIM_OK;
 }
 
@@ -1527,7 +1529,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   tile = std::min(tile, t_end - t_begin);
   tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
   p.tile_steps = tile;
-  const int coop = geom == GEOM_MESH && h->mesh_traversal != 1;
+  /* the cooperative traversal packs list positions and triangle numbers into 24 bits each (tie-break key of stage 3) */
+  const int coop = geom == GEOM_MESH && h->mesh_traversal != 1 && h->mesh.coop_ok;
   const int block = h->block_size;
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
   const size_t lds_fixed = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1)) * sizeof(double) +

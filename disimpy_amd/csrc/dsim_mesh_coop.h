@@ -17,8 +17,8 @@
  *             against the OWNER's cull box -> survivor pool;
  *   stage 3   any lane per survivor: fp64 Moller-Trumbore test with the OWNER's
  *             ray, minimum per owner by 64-bit LDS atomics on the bit pattern
- *             of d, ties resolved by a second atomic pass, the winner names its
- *             triangle;
+ *             of d, ties resolved by a second atomic pass whose key also names
+ *             the winner's triangle;
  *   stage 4   the owner fetches the unit normal of a hit within the step:
  *             reflection / crossing per walker, then the next pass for the
  *             walkers that hit something.
@@ -49,13 +49,12 @@
 #define COOP_CELLQ_CAP 256
 #define COOP_NO_SHIFT 0x20820u /* tag >> 14 when all three image numbers are 0 (stored + 32, 6 bits each) */
 
-/* Per-wavefront scratch in LDS (6.9 KB).  The owners' cull boxes and rays are NOT here: they
+/* Per-wavefront scratch in LDS (6.6 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
  * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
   unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)      0.5 KB */
-  unsigned long long best_key[64];      /* (visit << 32) | list position of the winner                  0.5 KB */
-  int best_tri[64];                     /* the winner's triangle (its owner fetches the unit normal)    0.25 KB */
+  unsigned long long best_key[64];      /* visit << 48 | list position << 24 | triangle of the winner   0.5 KB */
   uint2 cellq[COOP_CELLQ_CAP];          /* cell tasks {owner|visit|shifts, index into cell_range  or
                                            0x80000000 | subvoxel (range stored inline)} (1b -> 1c)      2.0 KB */
   /* the next four arrays (3.5 KB) also hold, between stages 1a and 1b, the subvoxel tasks
@@ -301,8 +300,8 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
 
 /* Stage 3: one trip of fp64 tests over the survivors [base, base + count) of the pool, count <= 64:
  * Moller-Trumbore test with the owner's ray, minimum per owner by 64-bit LDS atomics on the bit
- * pattern of d, ties resolved by a second atomic pass on (visit, list position), the winner
- * publishes its normal.  Runs several times per pass (a full trip whenever the pool holds 64
+ * pattern of d, ties resolved by a second atomic pass on (visit, list position, triangle).
+ * Runs several times per pass (a full trip whenever the pool holds 64
  * survivors, the remainder at the end); seen_d is best_d[lane] as of the previous call.  Every
  * lane of the wavefront must call this.  Leaves W->n_surv = base. */
 DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWave *W, int lane, unsigned long long &seen_d,
@@ -313,7 +312,10 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   uint4 sv = make_uint4(0u, 0u, 0u, 0u);
   if (valid) sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
   const int owner = (int)(sv.z & 63u);
-  const unsigned long long key = ((unsigned long long)((sv.z >> 6) & 255u) << 32) | (unsigned long long)sv.y;
+  /* (visit, list position, triangle): the first two order equal distances as the reference's loop does, the triangle
+   * rides along so that the minimum names the winner (24 bits each: the host sends meshes beyond that to the
+   * per-lane traversal) */
+  const unsigned long long key = ((unsigned long long)((sv.z >> 6) & 255u) << 48) | ((unsigned long long)sv.y << 24) | (unsigned long long)sv.x;
   V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
   const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
   double d = 0;
@@ -341,11 +343,8 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   wave_sync();
   const bool is_min = valid && d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner];
   if (is_min) atomicMin(&W->best_key[owner], key); /* pass B: among equal d the earliest (visit, position) */
-  wave_sync();
-  /* pass C: the winner names its triangle.  The owner fetches the precomputed unit normal in stage 4, and only if
-   * the hit lies within the step: most minima of a flush are beaten later or lie beyond the step's end, and a
-   * load here would stall every flush for it */
-  if (is_min && key == W->best_key[owner]) W->best_tri[owner] = (int)sv.x;
+  /* the owner reads the winner's triangle out of the key and fetches its precomputed unit normal in stage 4, and
+   * only if the hit lies within the step: most minima of a flush are beaten later or lie beyond the step's end */
   wave_sync();
   T_MARK(W, lane, 6);
 }
@@ -656,7 +655,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       const unsigned long long bd = W->best_d[lane];
       if (bd != 0x7ff0000000000000ULL) {
         d = __longlong_as_double((long long)bd);
-        if (d <= step_l) n = load_v3(ms.tri + (int64_t)W->best_tri[lane] * DS_TRI_STRIDE + 9);
+        if (d <= step_l) n = load_v3(ms.tri + (int64_t)(W->best_key[lane] & 0xffffffULL) * DS_TRI_STRIDE + 9);
       }
     }
     T_MARK(W, lane, 7);

@@ -21,7 +21,9 @@
  *   - walker indices: first_walker + n_walkers < 2^47 (depth of the RNG jump tables);
  *   - mesh: n_faces, n_refs and prod(n_sv) < 2^31, every n_sv[k] in [1, 4096]; the
  *     wavefront-cooperative traversal packs subvoxel coordinates in 10 bits, so with an
- *     n_sv[k] > 1024 every pass is done by the slower serial per-walker path (same results);
+ *     n_sv[k] > 1024 every pass is done by the slower serial per-walker path (same results),
+ *     and triangle numbers and list positions in 24 bits each, so a mesh with 2^24 or more faces
+ *     or list entries runs the per-lane traversal (mesh_traversal 1; same results);
  *     the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
  *     i.e. n_sv[0] + n_sv[1] + n_sv[2] below about 14 000;
  *   - spatial re-sorting of the walker slots (mesh substrates) needs 4096 <= n_walkers < 2^31
