@@ -24,28 +24,9 @@
 
 #include "../../include/dsim.h"
 #include "dsim_kernels.h"
+#include "dsim_mesh_host.h"
 
 #define DSIM_GAMMA 267.513e6 /* gradients.py:13 */
-
-/* ------------------------------------------------------------------ errors --- */
-
-static thread_local std::string g_err;
-
-static int fail(int code, const char *fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_err = buf;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                             \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) return fail(DSIM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
 
 extern "C" const char *dsim_last_error(void) { return g_err.c_str(); }
 extern "C" int dsim_abi_version(void) { return 1; }
@@ -198,24 +179,6 @@ __global__ void rng_init_kernel(uint64_t seed_s0, uint64_t seed_s1, uint64_t fir
 
 /* ------------------------------------------------------------------ handle --- */
 
-struct DevMesh {
-  double *tri = nullptr;
-  int2 *sv_range = nullptr;
-  int32_t *tri_idx = nullptr;
-  float4 *mrec = nullptr;
-  int2 *sv_micro = nullptr, *cell_range = nullptr;
-  int32_t *clear_idx = nullptr;
-  uint32_t *clear_bits = nullptr;
-  int clear_lf = 0;
-  double clear_frac = 0; /* share of the voxel's fine cells that are clear (diagnostic) */
-  double *bounds = nullptr;
-  int nx = 0, ny = 0, nz = 0;
-  double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
-  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; /* first and last boundary of every axis */
-  bool set = false;
-  bool coop_ok = false; /* fewer than 2^24 triangles and list entries */
-};
-
 struct dsim_sim {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -279,19 +242,6 @@ struct dsim_sim {
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
 };
-
-static void free_mesh(DevMesh &m) {
-  if (m.tri) (void)hipFree(m.tri);
-  if (m.sv_range) (void)hipFree(m.sv_range);
-  if (m.tri_idx) (void)hipFree(m.tri_idx);
-  if (m.mrec) (void)hipFree(m.mrec);
-  if (m.sv_micro) (void)hipFree(m.sv_micro);
-  if (m.cell_range) (void)hipFree(m.cell_range);
-  if (m.clear_idx) (void)hipFree(m.clear_idx);
-  if (m.clear_bits) (void)hipFree(m.clear_bits);
-  if (m.bounds) (void)hipFree(m.bounds);
-  m = DevMesh();
-}
 
 static int ensure_staging(dsim_sim *h, size_t bytes) {
   if (h->staging_bytes >= bytes) return DSIM_OK;
@@ -548,515 +498,6 @@ extern "C" int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, 
 
 /* ------------------------------------------------------------------- mesh --- */
 
-/* Does the triangle reach micro-cell (a, b, c) of a k^3 grid?  Conservative separating-axis test
- * (Akenine-Moller) in double precision against the cell inflated by 1e-6 of its size - far more
- * than any rounding of the test or of micro_cell().  Cells on the border of the grid extend to
- * infinity outwards, because the clamped cell map sends every coordinate beyond the subvoxel to
- * the border cell; for a well-conditioned test the (possibly infinite) cell is first clipped to
- * the triangle's own float32 bounding box, which cannot change the answer.  The bounding box
- * alone lists a triangle in every cell its box touches: on the neuron that is twice as many
- * records per cell as the triangles that actually pass through it. */
-static bool triangle_reaches_cell(const double *const tv[3], const float *tlo, const float *thi, const double org[3],
-                                  const double scale[3], const int abc[3], int k) {
-  double c[3], h[3];
-  for (int ax = 0; ax < 3; ax++) {
-    const double w = 1.0 / scale[ax], m = 1e-6 * w;
-    double lo = org[ax] + abc[ax] * w - m, hi = org[ax] + (abc[ax] + 1) * w + m;
-    const double blo = (double)tlo[ax] - m, bhi = (double)thi[ax] + m;
-    if (abc[ax] == 0 || lo < blo) lo = blo;         /* border cell: unbounded below; clip to the triangle's box */
-    if (abc[ax] == k - 1 || hi > bhi) hi = bhi;
-    if (!(hi > lo)) return true; /* cannot happen for a cell of the triangle's range; keep the record */
-    c[ax] = 0.5 * (lo + hi);
-    h[ax] = 0.5 * (hi - lo);
-  }
-  double v[3][3], e[3][3];
-  for (int q = 0; q < 3; q++)
-    for (int ax = 0; ax < 3; ax++) v[q][ax] = tv[q][ax] - c[ax];
-  for (int ax = 0; ax < 3; ax++) {
-    e[0][ax] = v[1][ax] - v[0][ax];
-    e[1][ax] = v[2][ax] - v[1][ax];
-    e[2][ax] = v[0][ax] - v[2][ax];
-  }
-  /* the 9 axes unit_i x e_j */
-  for (int j = 0; j < 3; j++)
-    for (int ax = 0; ax < 3; ax++) {
-      double a[3] = {0, 0, 0};
-      const int u = (ax + 1) % 3, w = (ax + 2) % 3;
-      a[u] = -e[j][w]; /* unit_ax x e = (0, -e_w, e_u) in the (ax, u, w) frame */
-      a[w] = e[j][u];
-      const double p0 = a[u] * v[0][u] + a[w] * v[0][w], p1 = a[u] * v[1][u] + a[w] * v[1][w], p2 = a[u] * v[2][u] + a[w] * v[2][w];
-      const double r = h[u] * std::fabs(a[u]) + h[w] * std::fabs(a[w]);
-      const double mn = std::min(p0, std::min(p1, p2)), mx = std::max(p0, std::max(p1, p2));
-      if (mn > r || mx < -r) return false;
-    }
-  /* the box faces */
-  for (int ax = 0; ax < 3; ax++) {
-    const double mn = std::min(v[0][ax], std::min(v[1][ax], v[2][ax])), mx = std::max(v[0][ax], std::max(v[1][ax], v[2][ax]));
-    if (mn > h[ax] || mx < -h[ax]) return false;
-  }
-  /* the triangle's plane */
-  const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
-  const double d = n[0] * v[0][0] + n[1] * v[0][1] + n[2] * v[0][2];
-  const double r = h[0] * std::fabs(n[0]) + h[1] * std::fabs(n[1]) + h[2] * std::fabs(n[2]);
-  if (std::fabs(d) > r) return false;
-  return true;
-}
-
-/* Triangle (v0, v1, v2) against the axis-aligned box of centre c and half-widths h: separating-axis
- * test (Akenine-Moller), in double precision on coordinates relative to the box centre.  Used with boxes
- * already inflated by far more than its own rounding, so "false" is certain. */
-static bool triangle_meets_box(const double *v0, const double *v1, const double *v2, const double c[3], const double h[3]) {
-  double v[3][3], e[3][3];
-  for (int ax = 0; ax < 3; ax++) {
-    v[0][ax] = v0[ax] - c[ax];
-    v[1][ax] = v1[ax] - c[ax];
-    v[2][ax] = v2[ax] - c[ax];
-  }
-  for (int ax = 0; ax < 3; ax++) {
-    const double mn = std::min(v[0][ax], std::min(v[1][ax], v[2][ax])), mx = std::max(v[0][ax], std::max(v[1][ax], v[2][ax]));
-    if (mn > h[ax] || mx < -h[ax]) return false;
-  }
-  for (int ax = 0; ax < 3; ax++) {
-    e[0][ax] = v[1][ax] - v[0][ax];
-    e[1][ax] = v[2][ax] - v[1][ax];
-    e[2][ax] = v[0][ax] - v[2][ax];
-  }
-  for (int j = 0; j < 3; j++)
-    for (int ax = 0; ax < 3; ax++) {
-      const int u = (ax + 1) % 3, w = (ax + 2) % 3;
-      const double au = -e[j][w], aw = e[j][u]; /* unit_ax x e_j */
-      const double p0 = au * v[0][u] + aw * v[0][w], p1 = au * v[1][u] + aw * v[1][w], p2 = au * v[2][u] + aw * v[2][w];
-      const double r = h[u] * std::fabs(au) + h[w] * std::fabs(aw);
-      if (std::min(p0, std::min(p1, p2)) > r || std::max(p0, std::max(p1, p2)) < -r) return false;
-    }
-  const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
-  const double d = n[0] * v[0][0] + n[1] * v[0][1] + n[2] * v[0][2];
-  const double r = h[0] * std::fabs(n[0]) + h[1] * std::fabs(n[1]) + h[2] * std::fabs(n[2]);
-  return std::fabs(d) <= r;
-}
-
-/* Clearance map.  The reference's reflect loop (simulations.py:924-997) ends a time step without a
- * reflection - and without drawing from the RNG - whenever no triangle is met within the step length:
- * `min_d > step_l`.  For a walker farther than step_l from EVERY triangle that is certain before any
- * look-up.  The map makes that test one bit: every subvoxel is cut into F^3 fine cells (F a power of two
- * <= 16, cells not smaller than half a step); a cell's bit is set when some triangle - in any periodic
- * image: the reference's look-ups wrap around the voxel whatever `periodic` says - meets the cell's box
- * inflated on all sides by
- *     reach = step_l * (1 + 1e-6)    (a hit at fp64 distance d <= step_l lies within that of the start)
- *           + 2e-3 * cell size       (the kernel's cell assignment near a face; rounding of this test).
- * The cube contains the ball, so a clear bit proves `min_d > step_l` for every walker in the cell and
- * every direction; a set bit proves nothing and the walker takes the full pass.  Results are therefore
- * bit-identical with and without the map (tests/test_gpu_production.py compares against the oracle,
- * which knows nothing of it). */
-static void build_clearance_map(const double *vertices, const int64_t *faces, int64_t n_faces, const double *const b3[3],
-                                const int64_t n_sv[3], double step_l, std::vector<int32_t> &clear_idx,
-                                std::vector<uint32_t> &clear_bits, int &lf_out, double &clear_frac) {
-  clear_idx.clear();
-  clear_bits.clear();
-  lf_out = 0;
-  clear_frac = 0;
-  double L[3], hsub_min = 1e300;
-  for (int k = 0; k < 3; k++) {
-    L[k] = b3[k][n_sv[k]] - b3[k][0];
-    if (!(L[k] > 0) || !std::isfinite(L[k])) return;
-    hsub_min = std::min(hsub_min, L[k] / (double)n_sv[k]);
-  }
-  if (!(step_l >= 0) || !std::isfinite(step_l)) return;
-  const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
-  int lf = 4;
-  while (lf > 0 && hsub_min / (double)(1 << lf) < 0.5 * step_l) lf--;
-  while (lf > 0 && (double)n_sub * (double)(1 << (3 * lf)) / 8.0 > 768e6) lf--; /* dense scratch bitmap <= 768 MB */
-  if ((double)n_sub * (double)(1 << (3 * lf)) / 8.0 > 768e6) return;
-  const int F = 1 << lf;
-  const size_t words = (size_t)std::max(1, (F * F * F) >> 5);
-  double hf[3], reach[3];
-  int64_t nf[3];
-  for (int k = 0; k < 3; k++) {
-    nf[k] = n_sv[k] * F;
-    hf[k] = L[k] / (double)nf[k];
-    reach[k] = step_l * (1.0 + 1e-6) + 2e-3 * hf[k];
-  }
-  /* work estimate: cells in the inflated bounding boxes; a mesh of huge triangles on a fine grid is not worth it */
-  double work = 0;
-  for (int64_t f = 0; f < n_faces; f++) {
-    double cells = 1;
-    for (int k = 0; k < 3; k++) {
-      const double a = vertices[faces[f * 3] * 3 + k], b = vertices[faces[f * 3 + 1] * 3 + k], c = vertices[faces[f * 3 + 2] * 3 + k];
-      const double ext = std::max(a, std::max(b, c)) - std::min(a, std::min(b, c)) + 2 * reach[k];
-      cells *= std::floor(ext / hf[k]) + 3;
-    }
-    work += cells;
-  }
-  if (work > 4e9) return;
-  std::unique_ptr<std::atomic<uint32_t>[]> dense(new std::atomic<uint32_t>[(size_t)n_sub * words]());
-  const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n_faces / 64));
-  std::atomic<int64_t> next(0);
-  auto worker = [&]() {
-    for (;;) {
-      const int64_t f0 = next.fetch_add(64);
-      if (f0 >= n_faces) break;
-      for (int64_t f = f0; f < std::min(n_faces, f0 + 64); f++) {
-        const double *v0 = &vertices[faces[f * 3] * 3], *v1 = &vertices[faces[f * 3 + 1] * 3], *v2 = &vertices[faces[f * 3 + 2] * 3];
-        int64_t lo[3], hi[3];
-        for (int k = 0; k < 3; k++) {
-          const double mn = std::min(v0[k], std::min(v1[k], v2[k])) - reach[k], mx = std::max(v0[k], std::max(v1[k], v2[k])) + reach[k];
-          /* one cell of slack: the SAT test decides.  A range longer than the axis visits a wrapped cell through
-           * several of its images - each has to be tested, the triangle may reach only one of them */
-          lo[k] = (int64_t)std::floor((mn - b3[k][0]) / hf[k]) - 1;
-          hi[k] = (int64_t)std::floor((mx - b3[k][0]) / hf[k]) + 1;
-        }
-        for (int64_t i = lo[0]; i <= hi[0]; i++)
-          for (int64_t j = lo[1]; j <= hi[1]; j++)
-            for (int64_t k = lo[2]; k <= hi[2]; k++) {
-              const int64_t ijk[3] = {i, j, k};
-              double c[3], h[3];
-              int64_t w[3];
-              for (int a = 0; a < 3; a++) {
-                c[a] = b3[a][0] + ((double)ijk[a] + 0.5) * hf[a]; /* the image cell, in the triangle's frame */
-                h[a] = 0.5 * hf[a] + reach[a];
-                w[a] = ((ijk[a] % nf[a]) + nf[a]) % nf[a];
-              }
-              if (!triangle_meets_box(v0, v1, v2, c, h)) continue;
-              const int64_t sv = ((w[0] >> lf) * n_sv[1] + (w[1] >> lf)) * n_sv[2] + (w[2] >> lf);
-              const unsigned bit = (unsigned)(((((w[0] & (F - 1)) << lf) | (w[1] & (F - 1))) << lf) | (w[2] & (F - 1)));
-              dense[(size_t)sv * words + (bit >> 5)].fetch_or(1u << (bit & 31), std::memory_order_relaxed);
-            }
-      }
-    }
-  };
-  if (n_thr <= 1) {
-    worker();
-  } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < n_thr; t++) th.emplace_back(worker);
-    for (auto &t : th) t.join();
-  }
-  clear_idx.assign((size_t)n_sub, -1);
-  const uint32_t used_mask = F * F * F >= 32 ? 0xffffffffu : ((1u << (F * F * F)) - 1u);
-  double set_bits = 0;
-  for (int64_t s = 0; s < n_sub; s++) {
-    bool any = false;
-    for (size_t w = 0; w < words; w++) any |= (dense[(size_t)s * words + w].load(std::memory_order_relaxed) & used_mask) != 0;
-    if (!any) continue;
-    clear_idx[(size_t)s] = (int32_t)(clear_bits.size() / words);
-    for (size_t w = 0; w < words; w++) {
-      const uint32_t v = dense[(size_t)s * words + w].load(std::memory_order_relaxed);
-      clear_bits.push_back(v);
-      set_bits += __builtin_popcount(v & used_mask);
-    }
-  }
-  if (clear_bits.empty()) clear_bits.push_back(0u);
-  lf_out = lf;
-  clear_frac = 1.0 - set_bits / ((double)n_sub * F * F * F);
-}
-
-/* Bounding box of the part of a triangle that lies inside micro-cell (a, b, c) of a k^3 grid - the cell inflated by
- * 1e-6 of its size and, on the border of the grid, extended to infinity, exactly as triangle_reaches_cell() takes it.
- * A record only has to answer for hits that happen inside ITS cell (a hit point lies in a visited cell in which the
- * triangle is registered, and it is that cell's record that must survive the box test), so the box of the clipped
- * triangle is a valid - and for the long slivers of a dendrite's skin far tighter - replacement of the triangle's
- * own box.  Sutherland-Hodgman clipping in double precision; the result is pushed outwards by another 1e-6 cell
- * sizes (rounding of the clipping) and intersected with the triangle's box.  Returns false (keep the triangle's box)
- * when the clipped polygon comes out empty, which only rounding can cause for a registered triangle. */
-static bool clipped_triangle_box(const double *const tv[3], const double org[3], const double scale[3], const int abc[3], int k,
-                                 double lo[3], double hi[3]) {
-  double poly[16][3], tmp[16][3];
-  int n = 3;
-  for (int q = 0; q < 3; q++)
-    for (int ax = 0; ax < 3; ax++) poly[q][ax] = tv[q][ax];
-  for (int ax = 0; ax < 3 && n > 0; ax++) {
-    const double w = 1.0 / scale[ax], m = 1e-6 * w;
-    for (int side = 0; side < 2 && n > 0; side++) {
-      if ((side == 0 && abc[ax] == 0) || (side == 1 && abc[ax] == k - 1)) continue; /* border cell: unbounded */
-      const double bound = side == 0 ? org[ax] + abc[ax] * w - m : org[ax] + (abc[ax] + 1) * w + m;
-      int out = 0;
-      for (int q = 0; q < n; q++) {
-        const double *p0 = poly[q], *p1 = poly[(q + 1) % n];
-        const double d0 = side == 0 ? p0[ax] - bound : bound - p0[ax], d1 = side == 0 ? p1[ax] - bound : bound - p1[ax];
-        if (d0 >= 0) {
-          for (int e = 0; e < 3; e++) tmp[out][e] = p0[e];
-          out++;
-        }
-        if ((d0 >= 0) != (d1 >= 0)) {
-          const double t = d0 / (d0 - d1);
-          for (int e = 0; e < 3; e++) tmp[out][e] = p0[e] + t * (p1[e] - p0[e]);
-          tmp[out][ax] = bound;
-          out++;
-        }
-      }
-      n = out;
-      for (int q = 0; q < n; q++)
-        for (int e = 0; e < 3; e++) poly[q][e] = tmp[q][e];
-    }
-  }
-  if (n == 0) return false;
-  for (int ax = 0; ax < 3; ax++) {
-    const double m = 1e-6 / scale[ax];
-    lo[ax] = hi[ax] = poly[0][ax];
-    for (int q = 1; q < n; q++) {
-      lo[ax] = std::min(lo[ax], poly[q][ax]);
-      hi[ax] = std::max(hi[ax], poly[q][ax]);
-    }
-    lo[ax] -= m;
-    hi[ax] += m;
-  }
-  return true;
-}
-
-static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
-                       int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
-                       const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l) {
-  if (!vertices || !faces || !xs || !ys || !zs || !n_sv || !subvoxel_indices || (!triangle_indices && n_refs))
-    return fail(DSIM_ERR_INVALID, "mesh: null argument");
-  if (n_faces <= 0 || n_vertices <= 0 || n_faces > INT32_MAX || n_refs > INT32_MAX || n_refs < 0)
-    return fail(DSIM_ERR_INVALID, "mesh: bad sizes");
-  for (int k = 0; k < 3; k++)
-    if (n_sv[k] < 1 || n_sv[k] > 4096) return fail(DSIM_ERR_INVALID, "mesh: n_sv[%d] = %lld out of range", k, (long long)n_sv[k]);
-  const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
-  if (n_sub > INT32_MAX) return fail(DSIM_ERR_INVALID, "mesh: too many subvoxels");
-  free_mesh(dm);
-  /* pre-gathered triangle records {A, B - A, C - A} (simulations.py:259-262 does these subtractions per candidate) */
-  std::vector<double> rec((size_t)n_faces * DS_TRI_STRIDE);
-  for (int64_t f = 0; f < n_faces; f++) {
-    int64_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
-    if (ia < 0 || ib < 0 || ic < 0 || ia >= n_vertices || ib >= n_vertices || ic >= n_vertices)
-      return fail(DSIM_ERR_INVALID, "mesh: face %lld references a vertex out of range", (long long)f);
-    for (int k = 0; k < 3; k++) {
-      double a = vertices[ia * 3 + k];
-      rec[f * DS_TRI_STRIDE + k] = a;
-      rec[f * DS_TRI_STRIDE + 3 + k] = vertices[ib * 3 + k] - a;
-      rec[f * DS_TRI_STRIDE + 6 + k] = vertices[ic * 3 + k] - a;
-    }
-    /* unit normal = normalize((A-B) x (A-C)) (simulations.py:77-97) with the device's own operations: cross3 and
-     * dot3 in the fma convention of dsim_device.h, correctly rounded sqrt (= ds_sqrt_dev, tested over the whole
-     * range), ds_div3 (same source on host and device).  A degenerate triangle gets the same NaNs as on the device. */
-    {
-      const double *e1 = &rec[f * DS_TRI_STRIDE + 3], *e2 = &rec[f * DS_TRI_STRIDE + 6];
-      double nx = std::fma(e1[1], e2[2], -(e1[2] * e2[1]));
-      double ny = std::fma(e1[2], e2[0], -(e1[0] * e2[2]));
-      double nz = std::fma(e1[0], e2[1], -(e1[1] * e2[0]));
-      const double len = std::sqrt(std::fma(nz, nz, std::fma(nx, nx, ny * ny)));
-      ds_div3(&nx, &ny, &nz, len);
-      rec[f * DS_TRI_STRIDE + 9] = nx;
-      rec[f * DS_TRI_STRIDE + 10] = ny;
-      rec[f * DS_TRI_STRIDE + 11] = nz;
-    }
-  }
-  std::vector<int2> ranges((size_t)n_sub);
-  for (int64_t s = 0; s < n_sub; s++) {
-    int64_t a = subvoxel_indices[s * 2], b = subvoxel_indices[s * 2 + 1];
-    if (a < 0 || b < a || b > n_refs) return fail(DSIM_ERR_INVALID, "mesh: subvoxel %lld has a bad range", (long long)s);
-    ranges[s] = make_int2((int)a, (int)b);
-  }
-
-  std::vector<int32_t> refs((size_t)std::max<int64_t>(n_refs, 1));
-  for (int64_t i = 0; i < n_refs; i++) {
-    if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
-    refs[i] = (int32_t)triangle_indices[i];
-  }
-  /* Micro-grids.  The reference's candidate set of a subvoxel is its whole list
-   * (up to 88 triangles per 4.3 um subvoxel on the neuron, several subvoxels per
-   * step), and a wavefront pays for its worst lane.  Every reference subvoxel
-   * with more than 8 references is therefore cut into k^3 micro-cells (k = 2, 4,
-   * 8); cell c holds the references of THIS subvoxel whose float32 AABB (rounded
-   * outward, clamped into the subvoxel) reaches c.  A query visits the cells
-   * reached by the segment's cull box (same clamped, monotone cell map), i.e. a
-   * subset of the reference's list that still contains every triangle whose AABB
-   * meets the cull box - the same exactness argument as make_cull_box(). Each
-   * 32-byte record = float32 AABB + triangle index + CSR position (tie order). */
-  double inv_h3[3];
-  {
-    const double *b3[3] = {xs, ys, zs};
-    for (int k = 0; k < 3; k++) {
-      double L = b3[k][n_sv[k]] - b3[k][0];
-      inv_h3[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
-    }
-  }
-  double sub_min = 1e300; /* smallest subvoxel edge */
-  for (int k = 0; k < 3; k++)
-    if (inv_h3[k] > 0) sub_min = std::min(sub_min, 1.0 / inv_h3[k]);
-  /* thresholds of the micro-grid (tuned on the neuron and the packed cylinders); DSIM_MICRO="t1,t2,t3,t4,min_cell"
-   * overrides them for tuning runs - results never depend on them */
-  int micro_t[4] = {2, 4, 16, 1 << 30};
-  double micro_min_cell = 1.5;
-  if (const char *env = getenv("DSIM_MICRO")) {
-    int a, b, c, d;
-    double m;
-    if (sscanf(env, "%d,%d,%d,%d,%lf", &a, &b, &c, &d, &m) == 5 && a >= 0 && b >= a && c >= b && d >= c && m > 0) {
-      micro_t[0] = a, micro_t[1] = b, micro_t[2] = c, micro_t[3] = d;
-      micro_min_cell = m;
-    }
-  }
-  std::vector<int2> sv_micro((size_t)n_sub);
-  std::vector<int2> cell_range;
-  std::vector<float4> mrec;
-  cell_range.push_back(make_int2(0, 0)); /* cell 0: shared by all empty subvoxels */
-  {
-    std::vector<std::vector<int32_t>> cells;
-    std::vector<float> lo3, hi3;
-    for (int64_t s = 0; s < n_sub; s++) {
-      const int begin = ranges[s].x, end = ranges[s].y, n_s = end - begin;
-      if (n_s <= 0) {
-        sv_micro[s] = make_int2(0, 0);
-        continue;
-      }
-      /* k^3 micro-cells (k = 2 / 4 / 8) for more than 2 / 4 / 16 references - round 2, with the cheaper
-       * branch-free record test: 5 % faster on the refined neuron than round 1's 4 / 16 / 64, itself 4.5 %
-       * faster than 8 / 32 / 128; {1,4,12}, {1,3,12}, {2,6,24} and k = 16 for the densest subvoxels are all
-       * within 0.5 % of it - but no cell smaller than 1.5 step lengths: a query box that spans
-       * several cells per axis multiplies the cell tasks (packed cylinders with 0.4 um
-       * subvoxels: 3.3e9 instead of 7.3e9 spin-steps/s with k = 2; 2.0 step lengths cost the neuron 5 %) */
-      int lk = n_s <= micro_t[0] ? 0 : (n_s <= micro_t[1] ? 1 : (n_s <= micro_t[2] ? 2 : (n_s <= micro_t[3] ? 3 : 4)));
-      while (lk > 0 && sub_min / (double)(1 << lk) < micro_min_cell * step_l) lk--;
-      const int k = 1 << lk;
-      const int64_t sx = s / (n_sv[1] * n_sv[2]), sy = (s / n_sv[2]) % n_sv[1], sz = s % n_sv[2];
-      const double org[3] = {xs[sx], ys[sy], zs[sz]};
-      const double scale[3] = {(double)k * inv_h3[0], (double)k * inv_h3[1], (double)k * inv_h3[2]};
-      cells.assign((size_t)k * k * k, std::vector<int32_t>());
-      lo3.assign((size_t)n_s * 3, 0.f);
-      hi3.assign((size_t)n_s * 3, 0.f);
-      for (int i = begin; i < end; i++) {
-        const int64_t *fc = &faces[(size_t)refs[i] * 3];
-        int c0[3], c1[3];
-        for (int ax = 0; ax < 3; ax++) {
-          double a = vertices[fc[0] * 3 + ax], b = vertices[fc[1] * 3 + ax], c = vertices[fc[2] * 3 + ax];
-          double mn = std::min(a, std::min(b, c)), mx = std::max(a, std::max(b, c));
-          float lo = std::nextafter((float)mn, -std::numeric_limits<float>::infinity());
-          float hi = std::nextafter((float)mx, std::numeric_limits<float>::infinity());
-          lo3[(size_t)(i - begin) * 3 + ax] = lo;
-          hi3[(size_t)(i - begin) * 3 + ax] = hi;
-          c0[ax] = micro_cell((double)lo, org[ax], scale[ax], k);
-          c1[ax] = micro_cell((double)hi, org[ax], scale[ax], k);
-        }
-        const double *tv[3] = {&vertices[fc[0] * 3], &vertices[fc[1] * 3], &vertices[fc[2] * 3]};
-        const float *tlo = &lo3[(size_t)(i - begin) * 3], *thi = &hi3[(size_t)(i - begin) * 3];
-        for (int a = c0[0]; a <= c1[0]; a++)
-          for (int b = c0[1]; b <= c1[1]; b++)
-            for (int c = c0[2]; c <= c1[2]; c++) {
-              const int abc[3] = {a, b, c};
-              if (k > 1 && !triangle_reaches_cell(tv, tlo, thi, org, scale, abc, k)) continue;
-              cells[((size_t)a * k + b) * k + c].push_back(i);
-            }
-      }
-      sv_micro[s] = make_int2((int)cell_range.size(), lk);
-      if (lk == 0) sv_micro[s] = make_int2(-((int)(mrec.size() / 3) + 1), n_s); /* single cell: range inline */
-      for (size_t ci = 0; ci < cells.size(); ci++) {
-        auto &cl = cells[ci];
-        const int abc[3] = {(int)(ci / ((size_t)k * k)), (int)((ci / k) % k), (int)(ci % k)};
-        int start = (int)(mrec.size() / 3);
-        for (int32_t i : cl) {
-          float lo[3], hi[3];
-          for (int ax = 0; ax < 3; ax++) lo[ax] = lo3[(size_t)(i - begin) * 3 + ax], hi[ax] = hi3[(size_t)(i - begin) * 3 + ax];
-          if (k > 1) { /* the box of the triangle's part inside this cell, float32 rounded outwards, never beyond the triangle's own */
-            const int64_t *fc3 = &faces[(size_t)refs[i] * 3];
-            const double *tv[3] = {&vertices[fc3[0] * 3], &vertices[fc3[1] * 3], &vertices[fc3[2] * 3]};
-            double clo[3], chi[3];
-            if (clipped_triangle_box(tv, org, scale, abc, k, clo, chi))
-              for (int ax = 0; ax < 3; ax++) {
-                const float l = std::nextafter((float)clo[ax], -std::numeric_limits<float>::infinity());
-                const float h2 = std::nextafter((float)chi[ax], std::numeric_limits<float>::infinity());
-                lo[ax] = std::max(lo[ax], l);
-                hi[ax] = std::min(hi[ax], h2);
-              }
-          }
-          float idx_bits, pos_bits;
-          int32_t ti = refs[i];
-          memcpy(&idx_bits, &ti, sizeof(float));
-          memcpy(&pos_bits, &i, sizeof(float));
-          /* supporting plane n.x = c in float32 (unit normal; c from the ROUNDED normal so that the
-           * float32 plane is self-consistent); a degenerate triangle gets n = 0, c = 0 and is never culled */
-          const double *r = &rec[(size_t)ti * DS_TRI_STRIDE];
-          double nx = r[4] * r[8] - r[5] * r[7], ny = r[5] * r[6] - r[3] * r[8], nz = r[3] * r[7] - r[4] * r[6];
-          double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
-          float fx = 0.f, fy = 0.f, fz = 0.f, fc = 0.f;
-          if (nn > 0 && std::isfinite(nn)) {
-            fx = (float)(nx / nn);
-            fy = (float)(ny / nn);
-            fz = (float)(nz / nn);
-            fc = (float)((double)fx * r[0] + (double)fy * r[1] + (double)fz * r[2]);
-          }
-          mrec.push_back(make_float4(lo[0], lo[1], lo[2], hi[0]));
-          mrec.push_back(make_float4(hi[1], hi[2], fx, fy));
-          mrec.push_back(make_float4(fz, fc, idx_bits, pos_bits));
-        }
-        cell_range.push_back(make_int2(start, (int)(mrec.size() / 3)));
-      }
-    }
-    if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
-  }
-  std::vector<double> bounds;
-  bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
-  bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
-  bounds.insert(bounds.end(), zs, zs + n_sv[2] + 1);
-  if (step_l > 0) { /* the walk's clearance map (not used by the fill kernel, which passes step_l = 0) */
-    std::vector<int32_t> cidx;
-    std::vector<uint32_t> cbits;
-    const double *bb[3] = {xs, ys, zs};
-    build_clearance_map(vertices, faces, n_faces, bb, n_sv, step_l, cidx, cbits, dm.clear_lf, dm.clear_frac);
-    if (!cidx.empty()) {
-      HIP_TRY(hipMalloc(&dm.clear_idx, cidx.size() * sizeof(int32_t)));
-      HIP_TRY(hipMalloc(&dm.clear_bits, cbits.size() * sizeof(uint32_t)));
-      HIP_TRY(hipMemcpyAsync(dm.clear_idx, cidx.data(), cidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipMemcpyAsync(dm.clear_bits, cbits.data(), cbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipStreamSynchronize(stream)); /* the host vectors die with this scope */
-    }
-  }
-  HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
-  HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
-  HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&dm.mrec, mrec.size() * sizeof(float4)));
-  HIP_TRY(hipMalloc(&dm.sv_micro, sv_micro.size() * sizeof(int2)));
-  HIP_TRY(hipMalloc(&dm.cell_range, cell_range.size() * sizeof(int2)));
-  HIP_TRY(hipMemcpyAsync(dm.mrec, mrec.data(), mrec.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.sv_micro, sv_micro.data(), sv_micro.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.cell_range, cell_range.data(), cell_range.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
-  HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.tri_idx, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.bounds, bounds.data(), bounds.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  dm.nx = (int)n_sv[0];
-  dm.ny = (int)n_sv[1];
-  dm.nz = (int)n_sv[2];
-  const double *b3[3] = {xs, ys, zs};
-  for (int k = 0; k < 3; k++) {
-    double L = b3[k][n_sv[k]] - b3[k][0];
-    dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
-    dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
-    dm.lo[k] = b3[k][0];
-    dm.hi[k] = b3[k][n_sv[k]];
-  }
-  dm.set = true;
-  dm.coop_ok = n_faces < (1 << 24) && n_refs < (1 << 24);
-  return DSIM_OK;
-}
-
-static MeshDev mesh_dev(const DevMesh &dm) {
-  MeshDev m;
-  m.tri = dm.tri;
-  m.sv_range = dm.sv_range;
-  m.tri_idx = dm.tri_idx;
-  m.mrec = dm.mrec;
-  m.sv_micro = dm.sv_micro;
-  m.cell_range = dm.cell_range;
-  m.bounds = dm.bounds;
-  m.clear_idx = dm.clear_idx;
-  m.clear_bits = dm.clear_bits;
-  m.clear_lf = dm.clear_lf;
-  m.nx = dm.nx;
-  m.ny = dm.ny;
-  m.nz = dm.nz;
-  m.inv_hx = dm.inv_h[0];
-  m.inv_hy = dm.inv_h[1];
-  m.inv_hz = dm.inv_h[2];
-  m.inv_lx = dm.inv_l[0];
-  m.inv_ly = dm.inv_l[1];
-  m.inv_lz = dm.inv_l[2];
-  m.x0 = dm.lo[0], m.y0 = dm.lo[1], m.z0 = dm.lo[2];
-  m.x1 = dm.hi[0], m.y1 = dm.hi[1], m.z1 = dm.hi[2];
-  return m;
-}
 
 extern "C" int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
                                        const double *ys, const double *zs, const int64_t n_sv[3], double step_l, int32_t *clear_idx,

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "dsim_kernels.h"
+#include "dsim_mesh_host.h"
 
 #define DSU_MAX_COLS 16
 
@@ -175,5 +176,143 @@ extern "C" int dsu_eval(int op, long long n, int n_in, const double *in, int n_o
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   if (d_xs) (void)hipFree(d_xs);
+  return 0;
+}
+
+/* ---- the mesh traversal on caller-supplied rays (tests/test_gpu_mesh_adversarial.py) --------------------------
+ * Walker i starts at r0[i] with direction step[i], remaining length step_l[i] and RNG state st[i] - no random
+ * step is drawn, so a test can aim rays at shared edges and vertices, along subvoxel boundary planes, at hits
+ * with d == step_l and into far periodic images.  mode 0: the wavefront-cooperative traversal, n_pass > 0 calls
+ * of coop_iteration() (flags bit 0 = the walker's reflect loop is over) or, n_pass == 0, as many as it takes,
+ * followed by the final advance of the position (flags bit 1 = iter_exc); mode 1: step_mesh(), the per-lane
+ * traversal (whole loop + advance only).  The CPU twin is dso_u_mesh_pass() in oracle/dsim_oracle.c. */
+struct MeshPassArgs {
+  long long n;
+  int n_pass, mode;
+  const double *r0, *step, *step_l;
+  const uint64_t *st;
+  double *r0_out, *step_out, *step_l_out;
+  uint64_t *st_out;
+  int32_t *flags;
+};
+
+__global__ __launch_bounds__(256) void mesh_pass_kernel(const WalkParams p, const MeshPassArgs a) {
+  extern __shared__ double lds[];
+  const int n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
+  for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) lds[i] = p.mesh.bounds[i];
+  __syncthreads();
+  const double *xs = lds, *ys = lds + p.mesh.nx + 1, *zs = lds + p.mesh.nx + p.mesh.ny + 2;
+  CoopWave *coop = reinterpret_cast<CoopWave *>(lds + ((n_bounds + 1) & ~1)) + (threadIdx.x >> 6);
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < a.n;
+  const int lane = (int)(threadIdx.x & 63);
+  V3 r = {0, 0, 0}, step = {1, 0, 0};
+  double sl = 0;
+  Rng rng = {1, 1};
+  if (live) {
+    r = load_v3(a.r0 + i * 3);
+    step = load_v3(a.step + i * 3);
+    sl = a.step_l[i];
+    rng.s0 = a.st[2 * i];
+    rng.s1 = a.st[2 * i + 1];
+  }
+  int flags = 0;
+  if (a.mode == 1) {
+    bool exc = false;
+    if (live) step_mesh(r, step, sl, p, xs, ys, zs, rng, exc);
+    flags = 1 | (exc ? 2 : 0);
+    sl = DS_NAN; /* step_mesh keeps the remaining length to itself */
+  } else {
+#ifdef DSIM_TIMERS
+    if (lane == 0) coop->tlast = 0;
+#endif
+    int64_t iter_idx = 0;
+    bool done = false;
+    for (int pass = 0; a.n_pass == 0 || pass < a.n_pass; pass++) {
+      if (__ballot(live && !done) == 0ULL) break;
+      const bool fin = coop_iteration(r, step, sl, iter_idx, live && !done, false, p, xs, ys, zs, rng, coop, lane);
+      if (live && !done && fin) done = true;
+    }
+    flags = done ? 1 : 0;
+    if (a.n_pass == 0) {
+      if (iter_idx >= p.max_iter) flags |= 2;
+      r.x = __builtin_fma(step.x, sl, r.x);
+      r.y = __builtin_fma(step.y, sl, r.y);
+      r.z = __builtin_fma(step.z, sl, r.z);
+    }
+  }
+  if (live) {
+    a.r0_out[i * 3] = r.x, a.r0_out[i * 3 + 1] = r.y, a.r0_out[i * 3 + 2] = r.z;
+    a.step_out[i * 3] = step.x, a.step_out[i * 3 + 1] = step.y, a.step_out[i * 3 + 2] = step.z;
+    a.step_l_out[i] = sl;
+    a.st_out[2 * i] = rng.s0, a.st_out[2 * i + 1] = rng.s1;
+    a.flags[i] = flags;
+  }
+}
+
+/* index_step_l: the step length the mesh index is laid out for (cell sizes; as dsim_create's step_l).  Returns 0 or -1. */
+extern "C" int dsu_mesh_pass(const double *vertices, long long n_vertices, const int64_t *faces, long long n_faces, const double *xs,
+                             const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                             const int64_t *triangle_indices, long long n_refs, double index_step_l, long long max_iter, double eps,
+                             double perm_prob, int mode, int n_pass, long long n, const double *r0, const double *step,
+                             const double *step_l, const uint64_t *st, double *r0_out, double *step_out, double *step_l_out,
+                             uint64_t *st_out, int32_t *flags) {
+  if (n <= 0 || !r0 || !step || !step_l || !st || !r0_out || !step_out || !step_l_out || !st_out || !flags || (mode != 0 && mode != 1) ||
+      n_pass < 0 || (mode == 1 && n_pass != 0)) {
+    g_unit_err = "dsu_mesh_pass: bad arguments";
+    return -1;
+  }
+  DevMesh dm;
+  std::vector<void *> dev;
+  auto fail_with = [&](const std::string &what) {
+    g_unit_err = what;
+    for (void *q : dev) (void)hipFree(q);
+    free_mesh(dm);
+    return -1;
+  };
+  if (upload_mesh(dm, nullptr, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs,
+                  index_step_l) != DSIM_OK)
+    return fail_with("upload_mesh: " + g_err);
+  auto to_dev = [&](const void *src, size_t bytes, void **out) -> bool {
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) return false;
+    dev.push_back(q);
+    if (src && hipMemcpy(q, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+    *out = q;
+    return true;
+  };
+  MeshPassArgs a = {};
+  a.n = n;
+  a.n_pass = n_pass;
+  a.mode = mode;
+  void *q[9];
+  const size_t v3 = (size_t)n * 3 * sizeof(double), v1 = (size_t)n * sizeof(double), vs = (size_t)n * 2 * sizeof(uint64_t);
+  if (!to_dev(r0, v3, &q[0]) || !to_dev(step, v3, &q[1]) || !to_dev(step_l, v1, &q[2]) || !to_dev(st, vs, &q[3]) ||
+      !to_dev(nullptr, v3, &q[4]) || !to_dev(nullptr, v3, &q[5]) || !to_dev(nullptr, v1, &q[6]) || !to_dev(nullptr, vs, &q[7]) ||
+      !to_dev(nullptr, (size_t)n * sizeof(int32_t), &q[8]))
+    return fail_with("dsu_mesh_pass: device memory");
+  a.r0 = (const double *)q[0], a.step = (const double *)q[1], a.step_l = (const double *)q[2], a.st = (const uint64_t *)q[3];
+  a.r0_out = (double *)q[4], a.step_out = (double *)q[5], a.step_l_out = (double *)q[6], a.st_out = (uint64_t *)q[7];
+  a.flags = (int32_t *)q[8];
+  WalkParams p = {};
+  p.n = n;
+  p.max_iter = max_iter;
+  p.eps = eps;
+  p.perm_prob = perm_prob;
+  p.mesh = mesh_dev(dm);
+  p.mesh.clear_idx = nullptr;
+  const int n_bounds = dm.nx + dm.ny + dm.nz + 3;
+  const size_t lds = (size_t)((n_bounds + 1) & ~1) * sizeof(double) + 4 * sizeof(CoopWave);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mesh_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return fail_with(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+  mesh_pass_kernel<<<(unsigned)((n + 255) / 256), 256, lds>>>(p, a);
+  if ((e = hipGetLastError()) != hipSuccess) return fail_with(std::string("launch: ") + hipGetErrorString(e));
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_with(std::string("sync: ") + hipGetErrorString(e));
+  if (hipMemcpy(r0_out, a.r0_out, v3, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(step_out, a.step_out, v3, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(step_l_out, a.step_l_out, v1, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(st_out, a.st_out, vs, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(flags, a.flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail_with("dsu_mesh_pass: copy back");
+  for (void *d : dev) (void)hipFree(d);
+  free_mesh(dm);
   return 0;
 }

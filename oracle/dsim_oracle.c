@@ -428,18 +428,26 @@ static void step_ellipsoid(int64_t tid, double *positions, dso_state *st, double
 /* Python's math.floor(x / n) for integers */
 static inline int64_t floor_div_as_float(int64_t x, int64_t n) { return (int64_t)floor((double)x / (double)n); }
 
-/* simulations.py:878-1002 */
-static void step_mesh(int64_t tid, double *positions, dso_state *st, double step_l, const dso_geom *g,
-                      uint8_t *iter_exc) {
-  double step[3], triangle[9], normal[3], shifts[3], temp_r0[3];
+/* simulations.py:924-997: the reflect loop of the mesh kernel for a given start r0, direction `step` and remaining
+ * length *step_l_io, as many iterations as it takes (max_passes <= 0) or at most max_passes of them.  Returns 1
+ * when the loop is over (no triangle within the remaining length, or the while-condition no longer holds), 0 when
+ * it was cut short by max_passes.  r0, step, *step_l_io, *iter_idx_io and the RNG state are left as the loop
+ * leaves them; the final advance of the position (simulations.py:1001-1002) is the caller's. */
+static int mesh_reflect_loop(double *r0, double *step, double *step_l_io, dso_state *st, const dso_geom *g,
+                             int64_t *iter_idx_io, int64_t max_passes) {
+  double triangle[9], normal[3], shifts[3], temp_r0[3];
   int64_t lls[3], uls[3];
-  double *r0 = &positions[tid * 3];
-  random_step(step, &st[tid]);
-  int check_intersection = 1;
-  int64_t iter_idx = 0;
+  double step_l = *step_l_io;
+  int64_t iter_idx = *iter_idx_io, passes = 0;
   int64_t closest_triangle_index = 0;
+  int over = 1;
   const int64_t nx = g->n_xs - 1, ny = g->n_ys - 1, nz = g->n_zs - 1;
-  while (check_intersection && step_l > 0 && iter_idx < g->max_iter) {
+  while (step_l > 0 && iter_idx < g->max_iter) { /* check_intersection leaves through `break` */
+    if (max_passes > 0 && passes == max_passes) {
+      over = 0;
+      break;
+    }
+    passes++;
     iter_idx++;
     double min_d = INFINITY;
     lls[0] = ll_subvoxel_overlap_periodic(g->xs, g->n_xs, r0[0], fma(step[0], step_l, r0[0]));
@@ -489,8 +497,8 @@ static void step_mesh(int64_t tid, double *positions, dso_state *st, double step
       }
     }
     if (min_d > step_l) {
-      check_intersection = 0;
-    } else if (g->perm_prob < uniform_f64(&st[tid])) {
+      break; /* check_intersection = False */
+    } else if (g->perm_prob < uniform_f64(st)) {
       get_triangle(closest_triangle_index, g->vertices, g->faces, triangle);
       triangle_normal(triangle, normal);
       reflection(r0, step, min_d, normal, g->epsilon);
@@ -502,6 +510,19 @@ static void step_mesh(int64_t tid, double *positions, dso_state *st, double step
       step_l -= min_d;
     }
   }
+  *step_l_io = step_l;
+  *iter_idx_io = iter_idx;
+  return over;
+}
+
+/* simulations.py:878-1002 */
+static void step_mesh(int64_t tid, double *positions, dso_state *st, double step_l, const dso_geom *g,
+                      uint8_t *iter_exc) {
+  double step[3];
+  double *r0 = &positions[tid * 3];
+  random_step(step, &st[tid]);
+  int64_t iter_idx = 0;
+  mesh_reflect_loop(r0, step, &step_l, &st[tid], g, &iter_idx, 0);
   if (iter_idx >= g->max_iter) iter_exc[tid] = 1;
   for (int i = 0; i < 3; i++) positions[tid * 3 + i] = fma(step[i], step_l, r0[i]);
 }
@@ -678,6 +699,86 @@ void dso_u_div3(double *v, double length) { ds_div3(&v[0], &v[1], &v[2], length)
 #endif
 double dso_u_cos(double x) { return DSO_COS(x); }
 size_t dso_sizeof_geom(void) { return sizeof(dso_geom); }
+
+/* The mesh kernel's reflect loop (simulations.py:924-997) on caller-supplied rays - the CPU twin of dsu_mesh_pass()
+ * in disimpy_amd/csrc/dsim_unit.hip, for the adversarial traversal tests (rays through shared edges and vertices,
+ * rays in subvoxel boundary planes, hits at d == step_l, far periodic images).  Walker i starts at r0[i] with
+ * direction step[i], remaining length step_l[i] and RNG state st[i]; n_pass > 0: at most that many iterations of
+ * the loop, nothing else (flags bit 0 = the loop is over); n_pass == 0: the whole loop, then the final advance
+ * r0 += step * step_l (simulations.py:1001-1002; flags bit 1 = iter_exc).  Arrays are updated in place. */
+void dso_u_mesh_pass(const dso_geom *g, int64_t n, int64_t n_pass, double *r0, double *step, double *step_l,
+                     dso_state *st, int32_t *flags) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    int64_t iter_idx = 0;
+    double sl = step_l[i];
+    const int over = mesh_reflect_loop(&r0[i * 3], &step[i * 3], &sl, &st[i], g, &iter_idx, n_pass);
+    int f = over ? 1 : 0;
+    if (n_pass == 0) {
+      if (iter_idx >= g->max_iter) f |= 2;
+      for (int k = 0; k < 3; k++) r0[i * 3 + k] = fma(step[i * 3 + k], sl, r0[i * 3 + k]);
+    }
+    step_l[i] = sl;
+    flags[i] = f;
+  }
+}
+
+/* How adversarial is a ray?  For the FIRST iteration of the reflect loop: ties[i] = number of DISTINCT triangles that
+ * attain the smallest positive d over the lists of all subvoxels in range (0 when that d is beyond step_l[i], i.e. no
+ * hit), lists[i] = number of list entries visited, subs[i] = number of subvoxels in range.  Test statistics only. */
+void dso_u_mesh_pass_stats(const dso_geom *g, int64_t n, const double *r0v, const double *stepv, const double *step_lv,
+                           int32_t *ties, int32_t *lists, int32_t *subs) {
+  const int64_t nx = g->n_xs - 1, ny = g->n_ys - 1, nz = g->n_zs - 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t w = 0; w < n; w++) {
+    const double *r0 = &r0v[w * 3], *step = &stepv[w * 3];
+    const double step_l = step_lv[w];
+    double triangle[9], temp_r0[3], sh[3];
+    int64_t lls[3], uls[3], at_min[64];
+    int n_at_min = 0, n_lists = 0, n_subs = 0;
+    double min_d = INFINITY;
+    const double *b3[3] = {g->xs, g->ys, g->zs};
+    const int64_t nb[3] = {g->n_xs, g->n_ys, g->n_zs}, ns[3] = {nx, ny, nz};
+    for (int k = 0; k < 3; k++) {
+      lls[k] = ll_subvoxel_overlap_periodic(b3[k], nb[k], r0[k], fma(step[k], step_l, r0[k]));
+      uls[k] = ul_subvoxel_overlap_periodic(b3[k], nb[k], r0[k], fma(step[k], step_l, r0[k]));
+    }
+    for (int64_t xi = lls[0]; xi < uls[0]; xi++)
+      for (int64_t yi = lls[1]; yi < uls[1]; yi++)
+        for (int64_t zi = lls[2]; zi < uls[2]; zi++) {
+          int64_t c[3] = {xi, yi, zi};
+          for (int k = 0; k < 3; k++) {
+            sh[k] = 0;
+            if (c[k] < 0 || c[k] > nb[k] - 2) {
+              const int64_t sn = floor_div_as_float(c[k], ns[k]);
+              c[k] -= sn * ns[k];
+              sh[k] = (double)sn * b3[k][nb[k] - 1];
+            }
+            temp_r0[k] = r0[k] - sh[k];
+          }
+          n_subs++;
+          const int64_t sv = c[0] * g->n_sv[1] * g->n_sv[2] + c[1] * g->n_sv[2] + c[2];
+          for (int64_t i = g->subvoxel_indices[sv * 2]; i < g->subvoxel_indices[sv * 2 + 1]; i++) {
+            n_lists++;
+            get_triangle(g->triangle_indices[i], g->vertices, g->faces, triangle);
+            const double d = ray_triangle_intersection_check(triangle, temp_r0, step);
+            if (!(d > 0)) continue;
+            if (d < min_d) {
+              min_d = d;
+              n_at_min = 0;
+            }
+            if (d == min_d) {
+              int seen = 0;
+              for (int q = 0; q < n_at_min; q++) seen |= at_min[q] == g->triangle_indices[i];
+              if (!seen && n_at_min < 64) at_min[n_at_min++] = g->triangle_indices[i];
+            }
+          }
+        }
+    ties[w] = min_d > step_l ? 0 : n_at_min;
+    lists[w] = n_lists;
+    subs[w] = n_subs;
+  }
+}
 
 /* ---- array form of the unit functions: the CPU side of tests/test_gpu_device_units.py ----
  * One call evaluates one device function of the reference on n independent inputs (column

@@ -104,6 +104,12 @@ class Oracle:
         lib.dso_u_logf.restype = C.c_float
         lib.dso_u_cos.argtypes = [C.c_double]
         lib.dso_u_cos.restype = C.c_double
+        lib.dso_u_mesh_pass.argtypes = [C.POINTER(Geom), C.c_int64, C.c_int64, _f64p, _f64p, _f64p, C.c_void_p,
+                                        C.POINTER(C.c_int32)]
+        lib.dso_u_mesh_pass.restype = None
+        _i32p = C.POINTER(C.c_int32)
+        lib.dso_u_mesh_pass_stats.argtypes = [C.POINTER(Geom), C.c_int64, _f64p, _f64p, _f64p, _i32p, _i32p, _i32p]
+        lib.dso_u_mesh_pass_stats.restype = None
 
     # ------------------------------------------------------------------ RNG
     def rng_states(self, n, seed, subsequence_start=0):
@@ -180,6 +186,34 @@ class Oracle:
             t_begin, t_end, _ptr(traj, _f64p) if want_traj else None, n_threads,
         )  # fmt: skip
         return phases, iter_exc, traj
+
+    def mesh_pass(self, g, r0, step, step_l, states, n_pass=1):
+        """The reflect loop of the mesh kernel (simulations.py:924-997) on caller-supplied rays: ``n_pass`` > 0
+        iterations at most, or (0) the whole loop plus the final advance.  Returns copies
+        (r0, step, step_l, states, flags); flags bit 0 = loop over, bit 1 = iter_exc (n_pass = 0 only)."""
+        r0 = np.array(r0, dtype=np.float64, order="C")
+        step = np.array(step, dtype=np.float64, order="C")
+        step_l = np.array(step_l, dtype=np.float64, order="C")
+        st = np.array(states, dtype=STATE_DTYPE, order="C")
+        n = len(step_l)
+        assert r0.shape == (n, 3) and step.shape == (n, 3) and len(st) == n
+        flags = np.zeros(n, dtype=np.int32)
+        self.lib.dso_u_mesh_pass(C.byref(g), n, n_pass, _ptr(r0, _f64p), _ptr(step, _f64p), _ptr(step_l, _f64p),
+                                 st.ctypes.data, flags.ctypes.data_as(C.POINTER(C.c_int32)))
+        return r0, step, step_l, st, flags
+
+    def mesh_pass_stats(self, g, r0, step, step_l):
+        """First iteration of the reflect loop: (distinct triangles tied at the minimum d of a hit, list entries
+        visited, subvoxels in range) per ray."""
+        r0 = np.ascontiguousarray(r0, dtype=np.float64)
+        step = np.ascontiguousarray(step, dtype=np.float64)
+        step_l = np.ascontiguousarray(step_l, dtype=np.float64)
+        n = len(step_l)
+        out = [np.zeros(n, dtype=np.int32) for _ in range(3)]
+        i32p = C.POINTER(C.c_int32)
+        self.lib.dso_u_mesh_pass_stats(C.byref(g), n, _ptr(r0, _f64p), _ptr(step, _f64p), _ptr(step_l, _f64p),
+                                       *[o.ctypes.data_as(i32p) for o in out])
+        return tuple(out)
 
     def signal(self, phases, iter_exc):
         M, N = phases.shape
