@@ -944,7 +944,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
    * accumulators (it stays at 128 VGPRs / 4 waves per SIMD), records the positions of every
    * step and phase_from_traj_kernel accumulates the phases from them - same operations, same
    * order, no replay of the walk for M > 32. */
-  const bool split_phase = geom == GEOM_MESH && h->mesh_traversal != 1 && (mb_all > COOP4_MAX_MB || h->recording);
+  const bool split_phase = geom == GEOM_MESH && h->mesh_traversal != 1 && h->mesh.coop_ok && (mb_all > COOP4_MAX_MB || h->recording);
   /* Everything else with more than 32 measurements: the first 32 in the walk kernel, which also
    * records the positions; the other passes accumulate from the positions (128 FMAs per walker
    * and step) instead of replaying RNG and geometry (480). */
@@ -970,7 +970,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   tile = std::min(tile, t_end - t_begin);
   tile = std::min(tile, std::max(1, (int)((60 * 1024) / (mb * 32))));
   p.tile_steps = tile;
-  /* the cooperative traversal packs list positions and triangle numbers into 24 bits each (tie-break key of stage 3) */
+  /* the cooperative traversal needs the reference's own uniform subvoxel grid (DevMesh::coop_ok) */
   const int coop = geom == GEOM_MESH && h->mesh_traversal != 1 && h->mesh.coop_ok;
   const int block = h->block_size;
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;

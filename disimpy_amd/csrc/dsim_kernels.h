@@ -72,12 +72,15 @@ struct MeshDev {
                               (simulations.py:989-990 recomputes it per reflection) */
   const int2 *sv_range;    /* [prod n_sv]   [start, end) into tri_idx    */
   const int32_t *tri_idx;  /* [n_refs]                                   */
-  const int2 *sv_micro;    /* [prod n_sv]   {0,0} empty | {-(first record + 1), count}: one cell, inline |
-                              {first cell, log2 k}: micro-grid of k^3 cells                          */
-  const int2 *cell_range;  /* [n_cells]     [start, end) into mrec                                  */
+  /* fine grid (dsim_mesh_host.h): every non-empty subvoxel is cut into k^3 cells, k = 1 << lk for the whole mesh */
+  const int32_t *sv_base;     /* [prod n_sv]  first cell of the subvoxel in cell_start, -1 = empty (lk == 0: unused,
+                                 cell_start is indexed by the subvoxel itself) */
+  const uint32_t *cell_start; /* [n_cells + 1] the records of cells c .. c+r-1 (a run along z inside one subvoxel) are
+                                 mrec[cell_start[c] .. cell_start[c + r]) */
   const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
-                              AABB rounded outward, float32 supporting plane n.x = c, triangle index,
-                              position in the reference's list */
+                              AABB (of the triangle's part inside the cell) rounded outward, float32 supporting
+                              plane n.x = c, triangle index, position in the reference's list */
+  int lk;
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   /* clearance map (dsim_hip.hip, build_clearance_map): every subvoxel is cut into F^3 fine cells, F = 1 << clear_lf;
    * a set bit = some triangle (of any periodic image) comes within one step length (+ margins) of some point of
@@ -246,15 +249,69 @@ DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   return c;
 }
 
-/* Candidate scan of one micro-cell: 4 records (128 bytes) are requested before the
- * first is examined, so that the L2 round trips overlap instead of queueing.
- * Ties: the reference keeps the FIRST candidate with the smallest d (strict <,
- * simulations.py:981); cells are visited out of list order, so within one
- * subvoxel an equal d wins only if its position in the reference's list is
- * lower than the current holder's (pass_pos = INT_MIN once a later subvoxel
- * starts: candidates of an earlier subvoxel always keep a tie). */
+struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
+  int llx, lly, llz, ulx, uly, ulz;
+};
+
+struct BestHit {
+  double d;
+  int tri;
+};
+
+/* One iteration of the reflect loop exactly as the reference does it (simulations.py:936-983): every triangle of
+ * every subvoxel in range, in the reference's order, no culling, the first smallest distance wins.  The fall-back
+ * of both traversals - for a walker whose work does not fit the wavefront's queues, and whenever two different
+ * triangles tie for the smallest distance, where only the reference's visiting order decides.  Kept small in
+ * registers: the occupancy of a kernel is set by its largest code path. */
+DSD void iteration_serial(const MeshDev &ms, const SubvoxelWalk &w, const V3 &r0, const V3 &step, const double *xs,
+                          const double *ys, const double *zs, BestHit &best) {
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
+  for (int xi = w.llx; xi < w.ulx; xi++) {
+    int x = xi, snx = 0;
+    if (x < 0 || x > nx - 1) {
+      snx = floor_div(x, nx);
+      x -= snx * nx;
+    }
+    for (int yi = w.lly; yi < w.uly; yi++) {
+      int y = yi, sny = 0;
+      if (y < 0 || y > ny - 1) {
+        sny = floor_div(y, ny);
+        y -= sny * ny;
+      }
+      for (int zi = w.llz; zi < w.ulz; zi++) {
+        int z = zi, snz = 0;
+        if (z < 0 || z > nz - 1) {
+          snz = floor_div(z, nz);
+          z -= snz * nz;
+        }
+        const int2 rg = ms.sv_range[(x * ny + y) * nz + z];
+        if (rg.y <= rg.x) continue;
+        STAT_LANE(8); /* subvoxel scanned serially by its owner */
+        STAT_WAVE(8);
+        const V3 tr0 = {r0.x - (double)snx * Lx, r0.y - (double)sny * Ly, r0.z - (double)snz * Lz};
+        for (int i = rg.x; i < rg.y; i++) {
+          const int ti = ms.tri_idx[i];
+          const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
+          const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
+          if (d > 0 && d < best.d) {
+            best.d = d;
+            best.tri = ti;
+          }
+        }
+      }
+    }
+  }
+}
+
+/* Candidate scan of a run of cells: 4 records (192 bytes) are requested before the first is
+ * examined, so that the L2 round trips overlap instead of queueing.  The cells are not visited in
+ * the reference's order, so a tie - two DIFFERENT triangles at the same smallest distance, of which
+ * the reference keeps the one its loops meet first (strict <, simulations.py:981) - is only
+ * detected here (`tie`); the caller then redoes the pass in the reference's order.  The same
+ * triangle met again (another cell, another subvoxel of the same image) returns the same d. */
 DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step,
-                         double &min_d, int &closest, int &pass_pos) {
+                         double &min_d, int &closest, bool &tie) {
   for (int i = begin; i < end; i += 4) {
     STAT_LANE(4);
     STAT_WAVE(4);
@@ -281,13 +338,17 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
       if (__builtin_fabsf(sm) - __builtin_fabsf(sh) > cb.tau) continue;
       STAT_LANE(6);
       STAT_WAVE(6);
-      int ti = __float_as_int(q2[u].z), pos = __float_as_int(q2[u].w);
+      int ti = __float_as_int(q2[u].z);
       const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
       double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
-      if (d > 0 && (d < min_d || (d == min_d && pos < pass_pos))) {
-        closest = ti;
-        min_d = d;
-        pass_pos = pos;
+      if (d > 0) {
+        if (d < min_d) {
+          closest = ti;
+          min_d = d;
+          tie = false;
+        } else if (d == min_d && ti != closest) {
+          tie = true;
+        }
       }
     }
   }
@@ -307,6 +368,7 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
     STAT_LANE(0);
     STAT_WAVE(0);
     double min_d = DS_INF;
+    bool tie = false;
     double ex = __builtin_fma(step.x, step_l, r0.x);
     double ey = __builtin_fma(step.y, step_l, r0.y);
     double ez = __builtin_fma(step.z, step_l, r0.z);
@@ -343,34 +405,45 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
           const int sv = (x * ny + y) * nz + z;
           STAT_LANE(1);
           STAT_WAVE(1);
-          const int2 mg = ms.sv_micro[sv];
-          if (mg.x == 0) continue; /* empty subvoxel */
+          const int lk = ms.lk;
+          int base = sv;
+          if (lk > 0) {
+            base = ms.sv_base[sv];
+            if (base < 0) continue; /* empty subvoxel */
+          }
           STAT_LANE(2);
           STAT_WAVE(2);
           V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
           const CullBox cb = make_cull_box(tr0, step, step_l);
-          int pass_pos = INT_MIN;
-          if (mg.x < 0) { /* single-cell subvoxel: record range stored inline */
+          if (lk == 0) {
             STAT_LANE(3);
             STAT_WAVE(3);
-            scan_candidates(ms, -mg.x - 1, -mg.x - 1 + mg.y, cb, tr0, step, min_d, closest, pass_pos);
+            scan_candidates(ms, (int)ms.cell_start[base], (int)ms.cell_start[base + 1], cb, tr0, step, min_d, closest, tie);
           } else {
-            const int k = 1 << mg.y;
+            const int k = 1 << lk;
             const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
             const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
             const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
             const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
             for (int a = a0; a <= a1; a++)
-              for (int b = b0; b <= b1; b++)
-                for (int c = c0; c <= c1; c++) {
-                  STAT_LANE(3);
-                  STAT_WAVE(3);
-                  const int2 cr = ms.cell_range[mg.x + (a * k + b) * k + c];
-                  scan_candidates(ms, cr.x, cr.y, cb, tr0, step, min_d, closest, pass_pos);
-                }
+              for (int b = b0; b <= b1; b++) {
+                STAT_LANE(3);
+                STAT_WAVE(3);
+                const int c = base + (a * k + b) * k; /* the cells c0 .. c1 of this column: one run of records */
+                scan_candidates(ms, (int)ms.cell_start[c + c0], (int)ms.cell_start[c + c1 + 1], cb, tr0, step, min_d, closest, tie);
+              }
           }
         }
       }
+    }
+    if (tie && min_d <= step_l) {
+      /* two different triangles at the same smallest distance: the reference keeps the one its loops meet first
+       * (simulations.py:981) - redo this pass in the reference's own order */
+      BestHit best = {DS_INF, 0};
+      SubvoxelWalk sw = {llx, lly, llz, ulx, uly, ulz};
+      iteration_serial(ms, sw, r0, step, xs, ys, zs, best);
+      min_d = best.d;
+      closest = best.tri;
     }
     if (min_d > step_l) {
       check = false;

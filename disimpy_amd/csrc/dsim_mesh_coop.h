@@ -7,77 +7,81 @@
  * reflect loop (simulations.py:924-997) is done for the 64 walkers of a
  * wavefront together, as flat loops over work queues that ALL lanes drain:
  *
- *   stage 1a  every walker ("owner"): subvoxel limits, float32 cull box, one
- *             task per subvoxel in range (reference order = visit number);
- *   stage 1b  any lane per subvoxel task: sv_micro look-up, the micro-cells the
- *             owner's box reaches -> cell tasks;
- *   stage 1c  any lane per cell task: cell_range look-up, the record range cut
- *             into 4-record items (slots from a wave prefix sum);
+ *   stage 1   every walker ("owner"): subvoxel limits, float32 cull box and -
+ *             by arithmetic alone, the fine grid has the same k for the whole
+ *             mesh - the fine cells its segment touches, as RUNS of cells along
+ *             z (the records of a run are contiguous).  The first run goes to
+ *             the queue slot of the owner's own lane, further runs behind;
+ *   stage 1c  any lane per run: sv_base + cell_start look-up, the record range
+ *             cut into 4-record items (slots from a wave prefix sum);
  *   stage 2   any lane per item: 4 records tested (float32 AABB + plane)
- *             against the OWNER's cull box -> survivor pool;
+ *             against the OWNER's cull box -> survivor pool (a survivor that
+ *             names a triangle its owner already has in the pool is dropped);
  *   stage 3   any lane per survivor: fp64 Moller-Trumbore test with the OWNER's
  *             ray, minimum per owner by 64-bit LDS atomics on the bit pattern
- *             of d, ties resolved by a second atomic pass whose key also names
- *             the winner's triangle;
+ *             of d; a second atomic pass names the winner's triangle and
+ *             notices when two DIFFERENT triangles share the minimum;
  *   stage 4   the owner fetches the unit normal of a hit within the step:
  *             reflection / crossing per walker, then the next pass for the
  *             walkers that hit something.
  *
- * Stages 1c-3 run in rounds (cells are expanded while the item queue has room,
+ * Stages 1c-3 run in rounds (runs are expanded while the item queue has room,
  * items are drained in full trips of 64, the survivor pool is flushed in full
  * trips of 64), so the queue sizes bound the LDS footprint, not the work per
- * pass.  The owners' segments (midpoint, half vector and margin: 7 floats, from which the
- * working lane rebuilds the cull box) and rays stay in the owners' registers and
- * are read with ds_bpermute; the kernel then fits 128 VGPRs and 7 KB of LDS per
- * wavefront, i.e. 4 wavefronts per SIMD.
+ * pass.  The owners' segments (midpoint, half vector and margin: 7 floats, from
+ * which the working lane rebuilds the cull box) and rays stay in the owners'
+ * registers and are read with ds_bpermute.
  *
- * Which triangles are tested, in fp64, against which ray is unchanged, and the
- * minimum keeps the reference's "first visited wins a tie" rule through the
- * explicit key (subvoxel visit number, position in the reference's list), so
- * results stay bit-identical to step_mesh and to the oracle.  A walker whose
- * work cannot be queued (more than 256 subvoxels in range, image shifts beyond
- * +-31 voxels, cell-task queue full, a single cell with more than 1024 records,
- * more than 128 survivors from one trip) is redone by its own lane exactly as
- * the reference does it (iteration_serial).
+ * Exactness.  Which (triangle, periodic image) pairs reach the fp64 test is a
+ * subset of what the reference tests (only list entries of subvoxels inside the
+ * segment's range are looked at, through the cells of THAT subvoxel) and a
+ * superset of the pairs that can return 0 < d <= step_l (culling is
+ * conservative with margins far above the rounding of the test).  The minimum
+ * over them is therefore the reference's min_d whenever that is <= step_l, and
+ * "beyond step_l" otherwise.  WHICH triangle attains it is unambiguous unless
+ * two different triangles return the same d bit for bit (a ray through a shared
+ * edge or vertex); the reference then keeps the one its loops meet first
+ * (strict <, simulations.py:981).  The queues do not preserve that order, so a
+ * tie is only DETECTED here and the pass of that one walker is redone by its own
+ * lane exactly as the reference does it (iteration_serial) - as is the work of
+ * a walker that does not fit the queues (more than 64 runs, image shifts beyond
+ * +-31 voxels, run queue full, a single run with more than 1024 records, more
+ * than 128 survivors from one trip).  tests/test_gpu_mesh_adversarial.py aims
+ * rays at exactly these cases.
  */
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
 #define COOP_ITEM_CAP 256
 #define COOP_SURV_CAP 128
-#define COOP_SVQ_CAP 448
-#define COOP_CELLQ_CAP 256
-#define COOP_NO_SHIFT 0x20820u /* tag >> 14 when all three image numbers are 0 (stored + 32, 6 bits each) */
+#define COOP_RUNQ_CAP 320 /* slots 0..63: the first run of owner 0..63; the other runs behind */
+#define COOP_MAX_RUNS 64  /* per owner and pass */
+#define COOP_NO_SHIFT 0x20820u /* (tag >> 6) & 0x3ffff when all three image numbers are 0 (stored + 32, 6 bits each) */
+#ifndef COOP_DEDUPE
+#define COOP_DEDUPE 1
+#endif
 
-/* Per-wavefront scratch in LDS (6.6 KB).  The owners' cull boxes and rays are NOT here: they
+/* Per-wavefront scratch in LDS (7.4 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
  * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
-  unsigned long long best_d[64];        /* smallest positive d (bit pattern orders like the value)      0.5 KB */
-  unsigned long long best_key[64];      /* visit << 48 | list position << 24 | triangle of the winner   0.5 KB */
-  uint2 cellq[COOP_CELLQ_CAP];          /* cell tasks {owner|visit|shifts, index into cell_range  or
-                                           0x80000000 | subvoxel (range stored inline)} (1b -> 1c)      2.0 KB */
-  /* the next four arrays (3.5 KB) also hold, between stages 1a and 1b, the subvoxel tasks
-   * {owner|visit|shifts, x | y << 10 | z << 20} */
-  uint2 items[COOP_ITEM_CAP];           /* items {first record | (count-1) << 30, owner|visit|shifts} (1c -> 2) */
-  unsigned surv_tri[COOP_SURV_CAP];     /* survivors (2 -> 3): triangle,                                       */
-  unsigned surv_pos[COOP_SURV_CAP];     /*   position in the reference's list,                                 */
-  unsigned surv_tag[COOP_SURV_CAP];     /*   owner|visit|shifts                                                */
-  unsigned char overflow[64];           /* some work of this owner did not fit a queue: redo serially          */
-  int n_surv, n_svq, pad[2];
-#ifdef DSIM_STATS
-  unsigned filt[64][4]; /* development: (owner, list position) pairs already among the survivors of this pass */
+  unsigned long long best_d[64];   /* smallest positive d (bit pattern orders like the value)                 0.5 KB */
+  unsigned best_tri[64];           /* a triangle that attains it (the smallest index among those seen)        0.25 KB */
+  uint2 runq[COOP_RUNQ_CAP];       /* runs {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell}  2.5 KB */
+  uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 30, owner | shifts << 6} (1c -> 2)  2.0 KB */
+  unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
+  unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6                                                   1.0 KB */
+#if COOP_DEDUPE
+  unsigned filt[64][2];            /* the last unshifted triangles this owner put into the pool (2-way, hashed) 0.5 KB */
 #endif
+  unsigned char overflow[64];      /* some work of this owner did not fit a queue: redo serially                     */
+  unsigned char tie[64];           /* two different triangles share this owner's smallest d: the reference's order decides */
+  int n_surv, pad[3];
 #ifdef DSIM_TIMERS
   unsigned long long tacc[16], tlast;
   unsigned long long tpad;
 #endif
 };
-static_assert(COOP_SVQ_CAP * 8 <= COOP_ITEM_CAP * 8 + COOP_SURV_CAP * 12, "subvoxel tasks share the item and survivor queues");
-
-DSD uint2 *coop_items(CoopWave *W) { return W->items; }
-DSD uint2 *coop_svq(CoopWave *W) { return W->items; }
-DSD uint2 *coop_cellq(CoopWave *W) { return W->cellq; }
 
 /* inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS crossbar): Kogge-Stone
  * inside every row of 16 lanes, then the row totals are carried into the following rows */
@@ -119,25 +123,6 @@ DSD CullBox shift_cull_box(const CullBox &c, double shx, double shy, double shz)
   return o;
 }
 
-/* (visit, position) of the current best candidate; a candidate with an equal d wins only
- * if it comes earlier in the reference's visiting order (simulations.py:937-983) */
-struct BestHit {
-  double d;
-  int visit, pos, tri;
-  bool have_n; /* n holds E1 x E2 of tri (published by the lane that tested it) */
-  V3 n;
-};
-
-DSD void offer_hit(BestHit &b, double d, int visit, int pos, int tri) {
-  if (d > 0 && (d < b.d || (d == b.d && (visit < b.visit || (visit == b.visit && pos < b.pos))))) {
-    b.d = d;
-    b.visit = visit;
-    b.pos = pos;
-    b.tri = tri;
-    b.have_n = false;
-  }
-}
-
 /* > 0 when the record can be skipped - ONE number, no branches or mask arithmetic: the max over (a) the six box
  * gaps (a positive gap on any axis separates the triangle's box from the segment's) and (b) how far beyond the
  * margin tau the whole segment lies on one side of the triangle's plane: with the midpoint m and the half vector
@@ -153,116 +138,25 @@ DSD float cull_margin(const float4 &q0, const float4 &q1, const float4 &q2, cons
   return __builtin_fmaxf(__builtin_fmaxf(g1, g2), side);
 }
 
-struct SubvoxelWalk { /* the subvoxel ranges of one reflect-loop iteration (simulations.py:929-934) */
-  int llx, lly, llz, ulx, uly, ulz;
+/* the fine cells of a pass: global fine coordinates (subvoxel * k + cell, any periodic image) per axis, both ends
+ * inclusive, already clamped into the first / last subvoxel of the reference's range */
+struct FineRange {
+  int a0, a1, b0, b1, c0, c1;
 };
 
-/* Fallback: the whole iteration of one walker done by its own lane exactly as the reference does
- * it (simulations.py:936-983): every triangle of every subvoxel in range, no culling.  Kept
- * deliberately small in registers - the occupancy of the kernel is set by its largest code path
- * and this one runs only when a walker's work does not fit the wavefront's queues. */
-DSD void iteration_serial(const MeshDev &ms, const SubvoxelWalk &w, const V3 &r0, const V3 &step, const double *xs,
-                          const double *ys, const double *zs, BestHit &best) {
-  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
-  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
-  int visit = 0;
-  for (int xi = w.llx; xi < w.ulx; xi++) {
-    int x = xi, snx = 0;
-    if (x < 0 || x > nx - 1) {
-      snx = floor_div(x, nx);
-      x -= snx * nx;
-    }
-    for (int yi = w.lly; yi < w.uly; yi++) {
-      int y = yi, sny = 0;
-      if (y < 0 || y > ny - 1) {
-        sny = floor_div(y, ny);
-        y -= sny * ny;
-      }
-      for (int zi = w.llz; zi < w.ulz; zi++) {
-        int z = zi, snz = 0;
-        if (z < 0 || z > nz - 1) {
-          snz = floor_div(z, nz);
-          z -= snz * nz;
-        }
-        const int v = visit++;
-        const int2 rg = ms.sv_range[(x * ny + y) * nz + z];
-        if (rg.y <= rg.x) continue;
-        STAT_LANE(8); /* subvoxel scanned serially by its owner */
-        STAT_WAVE(8);
-        const V3 tr0 = {r0.x - (double)snx * Lx, r0.y - (double)sny * Ly, r0.z - (double)snz * Lz};
-        for (int i = rg.x; i < rg.y; i++) {
-          const int ti = ms.tri_idx[i];
-          const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
-          const double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
-          offer_hit(best, d, v, i, ti);
-        }
-      }
-    }
-  }
-}
-
-/* Stage 1a: the owner lists the subvoxels of its iteration (reference order = visit number) as
- * tasks for the wavefront.  Returns false when they cannot be encoded or queued (the caller
- * then does the iteration serially). */
-DSD bool push_subvoxels(const MeshDev &ms, const SubvoxelWalk &w, int nsub, CoopWave *W, int lane) {
-  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
-  if (nx > 1024 || ny > 1024 || nz > 1024) return false;
-  /* image shifts must fit 6 bits each */
-  if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return false;
-  const int base = atomicAdd(&W->n_svq, nsub);
-  uint2 *q = coop_svq(W);
-  if (base + nsub > COOP_SVQ_CAP) {
-    /* queue full: neutralise the part of the reservation that lies inside the queue */
-    for (int j = base; j < COOP_SVQ_CAP; j++) q[j] = make_uint2(0xffffffffu, 0u);
-    return false;
-  }
-  /* wrapped index and image number of the first subvoxel on every axis; the loop then steps
-   * through the range z-fastest (simulations.py:936-938) without further divisions */
-  int x = w.llx, snx = 0, y0 = w.lly, sny0 = 0, z0 = w.llz, snz0 = 0;
-  if (x < 0 || x > nx - 1) {
-    snx = floor_div(x, nx);
-    x -= snx * nx;
-  }
-  if (y0 < 0 || y0 > ny - 1) {
-    sny0 = floor_div(y0, ny);
-    y0 -= sny0 * ny;
-  }
-  if (z0 < 0 || z0 > nz - 1) {
-    snz0 = floor_div(z0, nz);
-    z0 -= snz0 * nz;
-  }
-  int y = y0, sny = sny0, z = z0, snz = snz0, yi = w.lly, zi = w.llz;
-  for (unsigned v = 0; v < (unsigned)nsub; v++) {
-    q[base + v] = make_uint2((unsigned)lane | (v << 6) | ((unsigned)(snx + 32) << 14) | ((unsigned)(sny + 32) << 20) |
-                                 ((unsigned)(snz + 32) << 26),
-                             (unsigned)x | ((unsigned)y << 10) | ((unsigned)z << 20));
-    zi++, z++;
-    if (z == nz) z = 0, snz++;
-    if (zi == w.ulz) {
-      zi = w.llz, z = z0, snz = snz0;
-      yi++, y++;
-      if (y == ny) y = 0, sny++;
-      if (yi == w.uly) {
-        yi = w.lly, y = y0, sny = sny0;
-        x++;
-        if (x == nx) x = 0, snx++;
-      }
-    }
-  }
-  return true;
-}
-
 /* Both periodic subvoxel limits of one axis in float32, for the common case that decides itself: the boundaries
- * are np.linspace(x0, x0 + L, n + 1), image k of boundary i sits at (k n + i) h, so for a coordinate that is NOT
+ * are np.linspace(0, L, n + 1), image k of boundary i sits at (k n + i) h, so for a coordinate that is NOT
  * within 1e-4 subvoxel widths of any boundary the reference's scans (simulations.py:616-679) end at
- * ll = floor(t_min), ul = floor(t_max) + 1 with t = (x - x0) / h - whatever arithmetic produced t, as long as its
+ * ll = floor(t_min), ul = floor(t_max) + 1 with t = x / h - whatever arithmetic produced t, as long as its
  * error stays below that distance.  t is the fp64 product rounded once to float32 (relative error 6e-8).  The
  * caller accepts when `edge` < 0.4999 on every axis (both fractional parts farther than 1e-4 from 0 and 1) and
  * the sum of all six |t| is below 1500 (so every |t| < 1500 and its error < 9e-5); otherwise - too close to a
- * boundary, too far out, or not a number - it takes the exact fp64 path. */
-DSD void subvoxel_limits_f32(double x0, double inv_h, double x1, double x2, int &ll, int &ul, float &edge, float &reach) {
+ * boundary, too far out, or not a number - it takes the exact fp64 path.  tmin / tmax (subvoxel units) also
+ * place the segment on the fine grid. */
+DSD void subvoxel_limits_f32(double x0, double inv_h, double x1, double x2, int &ll, int &ul, float &edge, float &reach, float &tmin,
+                             float &tmax) {
   const float t1 = (float)((x1 - x0) * inv_h), t2 = (float)((x2 - x0) * inv_h);
-  const float tmin = __builtin_fminf(t1, t2), tmax = __builtin_fmaxf(t1, t2);
+  tmin = __builtin_fminf(t1, t2), tmax = __builtin_fmaxf(t1, t2);
   const float fmin = __builtin_floorf(tmin), fmax = __builtin_floorf(tmax);
   ll = (int)fmin;
   ul = (int)fmax + 1;
@@ -270,38 +164,109 @@ DSD void subvoxel_limits_f32(double x0, double inv_h, double x1, double x2, int 
   edge = __builtin_fmaxf(__builtin_fabsf((tmin - fmin) - 0.5f), __builtin_fabsf((tmax - fmax) - 0.5f));
   reach = __builtin_fabsf(t1) + __builtin_fabsf(t2); /* an addition: NaN survives it (min / max would drop it) */
 }
+DSD void subvoxel_limits_f32(double x0, double inv_h, double x1, double x2, int &ll, int &ul, float &edge, float &reach) {
+  float tmin, tmax;
+  subvoxel_limits_f32(x0, inv_h, x1, x2, ll, ul, edge, reach, tmin, tmax);
+}
 
-/* subvoxel ranges (simulations.py:929-934) and cull box of the remaining segment */
+/* The fine cells of one axis: the segment's extent [tmin, tmax] in subvoxel units times k, widened by far more than
+ * the error of t (half a float32 ulp of t, i.e. <= 6e-8 `reach` subvoxels) and of the index's own cell assignment
+ * (micro_cell() in fp64; cells registered with an inflation of 1e-6), then clamped into the first and the last
+ * subvoxel of the reference's range [ll, ul): together with "border cells extend to infinity" of the index this
+ * visits, in EVERY subvoxel of the range, the cells of the segment's box clamped into that subvoxel.  Any superset of
+ * the exact cells is valid (an extra cell only costs its records a look). */
+DSD void fine_limits(float tmin, float tmax, float reach, int ll, int ul, int lk, int &f0, int &f1) {
+  const int k = 1 << lk;
+  const float kf = (float)k;
+  const float mk = __builtin_fmaf(reach, 1.2e-7f * kf, __builtin_fmaf(1e-4f, kf, 1e-3f));
+  const int lo = ll * k, hi = (ul - 1) * k;
+  /* float -> int conversions saturate and send NaN to 0; the clamps make any value safe */
+  f0 = min(max((int)__builtin_floorf(__builtin_fmaf(tmin, kf, -mk)), lo), lo + k - 1);
+  f1 = min(max((int)__builtin_floorf(__builtin_fmaf(tmax, kf, mk)), hi), hi + k - 1);
+  f1 = max(f1, f0); /* only ever changes a value that NaN input produced inside a single subvoxel */
+}
+
+/* subvoxel ranges (simulations.py:929-934), cull box and fine cells of the remaining segment */
 DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double step_l, const double *xs, const double *ys,
-                       const double *zs, SubvoxelWalk &sw, CullBox &cb0) {
+                       const double *zs, SubvoxelWalk &sw, CullBox &cb0, FineRange &fr) {
   const double ex = __builtin_fma(step.x, step_l, r0.x);
   const double ey = __builtin_fma(step.y, step_l, r0.y);
   const double ez = __builtin_fma(step.z, step_l, r0.z);
   cb0 = make_cull_box(r0, step, step_l);
-  {
-    float e0, e1, e2, q0, q1, q2;
-    subvoxel_limits_f32(ms.x0, ms.inv_hx, r0.x, ex, sw.llx, sw.ulx, e0, q0);
-    subvoxel_limits_f32(ms.y0, ms.inv_hy, r0.y, ey, sw.lly, sw.uly, e1, q1);
-    subvoxel_limits_f32(ms.z0, ms.inv_hz, r0.z, ez, sw.llz, sw.ulz, e2, q2);
-    /* decided on all three axes: 99.9 % of the segments (NaN fails both comparisons) */
-    if (__builtin_fmaxf(__builtin_fmaxf(e0, e1), e2) < 0.4999f && (q0 + q1) + q2 < 1500.0f) return;
+  float e0, e1, e2, q0, q1, q2, tn0, tx0, tn1, tx1, tn2, tx2;
+  subvoxel_limits_f32(ms.x0, ms.inv_hx, r0.x, ex, sw.llx, sw.ulx, e0, q0, tn0, tx0);
+  subvoxel_limits_f32(ms.y0, ms.inv_hy, r0.y, ey, sw.lly, sw.uly, e1, q1, tn1, tx1);
+  subvoxel_limits_f32(ms.z0, ms.inv_hz, r0.z, ez, sw.llz, sw.ulz, e2, q2, tn2, tx2);
+  /* decided on all three axes: 99.9 % of the segments (NaN fails both comparisons) */
+  if (!(__builtin_fmaxf(__builtin_fmaxf(e0, e1), e2) < 0.4999f && (q0 + q1) + q2 < 1500.0f)) {
+    const bool fx = subvoxel_limits_fast(xs, ms.nx, ms.x0, ms.x1, ms.inv_hx, ms.inv_lx, r0.x, ex, sw.llx, sw.ulx);
+    const bool fy = subvoxel_limits_fast(ys, ms.ny, ms.y0, ms.y1, ms.inv_hy, ms.inv_ly, r0.y, ey, sw.lly, sw.uly);
+    const bool fz = subvoxel_limits_fast(zs, ms.nz, ms.z0, ms.z1, ms.inv_hz, ms.inv_lz, r0.z, ez, sw.llz, sw.ulz);
+    if (!(fx && fy && fz)) {
+      sw.llx = ll_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+      sw.lly = ll_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+      sw.llz = ll_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+      sw.ulx = ul_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
+      sw.uly = ul_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
+      sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+    }
   }
-  const bool fx = subvoxel_limits_fast(xs, ms.nx, ms.x0, ms.x1, ms.inv_hx, ms.inv_lx, r0.x, ex, sw.llx, sw.ulx);
-  const bool fy = subvoxel_limits_fast(ys, ms.ny, ms.y0, ms.y1, ms.inv_hy, ms.inv_ly, r0.y, ey, sw.lly, sw.uly);
-  const bool fz = subvoxel_limits_fast(zs, ms.nz, ms.z0, ms.z1, ms.inv_hz, ms.inv_lz, r0.z, ez, sw.llz, sw.ulz);
-  if (fx && fy && fz) return;
-  sw.llx = ll_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
-  sw.lly = ll_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
-  sw.llz = ll_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
-  sw.ulx = ul_subvoxel_overlap_periodic(xs, ms.nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
-  sw.uly = ul_subvoxel_overlap_periodic(ys, ms.ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
-  sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
+  fine_limits(tn0, tx0, q0, sw.llx, sw.ulx, ms.lk, fr.a0, fr.a1);
+  fine_limits(tn1, tx1, q1, sw.lly, sw.uly, ms.lk, fr.b0, fr.b1);
+  fine_limits(tn2, tx2, q2, sw.llz, sw.ulz, ms.lk, fr.c0, fr.c1);
+}
+
+/* number of runs of the pass (0: the reference's range is empty, nothing is visited), or -1 when the walker cannot be
+ * queued: image shifts must fit 6 bits each, and no more than COOP_MAX_RUNS runs per owner */
+DSD int count_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f) {
+  if (w.ulx <= w.llx || w.uly <= w.lly || w.ulz <= w.llz) return 0;
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return -1;
+  const int na = f.a1 - f.a0 + 1, nb = f.b1 - f.b0 + 1, nc = w.ulz - w.llz;
+  if (na > COOP_MAX_RUNS || nb > COOP_MAX_RUNS || nc > COOP_MAX_RUNS) return -1;
+  const int n = na * nb * nc;
+  return n > COOP_MAX_RUNS ? -1 : n;
+}
+
+/* wrapped subvoxel coordinate and image number of an absolute subvoxel coordinate */
+DSD void wrap_subvoxel(int s, int n, int &x, int &sn) {
+  x = s, sn = 0;
+  if (s < 0 || s > n - 1) {
+    sn = floor_div(s, n);
+    x = s - sn * n;
+  }
+}
+
+/* Stage 1: the owner writes its runs - for every (x, y) fine column of its range and every subvoxel along z one run
+ * of cells - into the run queue: the first into slot `lane`, the others from slot `extra` on. */
+DSD void push_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, CoopWave *W, int lane, int extra) {
+  const int lk = ms.lk, k = 1 << lk, km = k - 1;
+  int slot = lane;
+  for (int a = f.a0; a <= f.a1; a++) {
+    int x, snx;
+    wrap_subvoxel(a >> lk, ms.nx, x, snx);
+    for (int b = f.b0; b <= f.b1; b++) {
+      int y, sny;
+      wrap_subvoxel(b >> lk, ms.ny, y, sny);
+      const unsigned col = (unsigned)((((a & km) << lk) | (b & km)) << lk);
+      for (int zi = w.llz; zi < w.ulz; zi++) {
+        int z, snz;
+        wrap_subvoxel(zi, ms.nz, z, snz);
+        const int cs = max(f.c0, zi * k), ce = min(f.c1, zi * k + km);
+        const unsigned sv = (unsigned)((x * ms.ny + y) * ms.nz + z);
+        W->runq[slot] = make_uint2((unsigned)lane | ((unsigned)(snx + 32) << 6) | ((unsigned)(sny + 32) << 12) | ((unsigned)(snz + 32) << 18) |
+                                       ((unsigned)(ce - cs) << 24),
+                                   (sv << (3 * lk)) + (col | (unsigned)(cs & km)));
+        slot = slot == lane ? extra : slot + 1;
+      }
+    }
+  }
 }
 
 /* Stage 3: one trip of fp64 tests over the survivors [base, base + count) of the pool, count <= 64:
  * Moller-Trumbore test with the owner's ray, minimum per owner by 64-bit LDS atomics on the bit
- * pattern of d, ties resolved by a second atomic pass on (visit, list position, triangle).
- * Runs several times per pass (a full trip whenever the pool holds 64
+ * pattern of d; a second atomic pass records a triangle that attains the minimum and flags the owner
+ * when two different triangles do.  Runs several times per pass (a full trip whenever the pool holds 64
  * survivors, the remainder at the end); seen_d is best_d[lane] as of the previous call.  Every
  * lane of the wavefront must call this.  Leaves W->n_surv = base. */
 DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWave *W, int lane, unsigned long long &seen_d,
@@ -309,42 +274,40 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1;
   const int idx = base + lane;
   const bool valid = lane < count;
-  uint4 sv = make_uint4(0u, 0u, 0u, 0u);
-  if (valid) sv = make_uint4(W->surv_tri[idx], W->surv_pos[idx], W->surv_tag[idx], 0u);
-  const int owner = (int)(sv.z & 63u);
-  /* (visit, list position, triangle): the first two order equal distances as the reference's loop does, the triangle
-   * rides along so that the minimum names the winner (24 bits each: the host sends meshes beyond that to the
-   * per-lane traversal) */
-  const unsigned long long key = ((unsigned long long)((sv.z >> 6) & 255u) << 48) | ((unsigned long long)sv.y << 24) | (unsigned long long)sv.x;
+  unsigned tri = 0u, tag = 0u;
+  if (valid) tri = W->surv_tri[idx], tag = W->surv_tag[idx];
+  const int owner = (int)(tag & 63u);
   V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
   const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
   double d = 0;
   if (valid) { /* pass A: distances, atomic minimum of d */
     STAT_LANE(6);
     STAT_WAVE(6);
-    if ((sv.z >> 14) != COOP_NO_SHIFT) { /* x - 0.0 == x bit for bit, so the unshifted case skips the arithmetic */
-      const int snx = (int)((sv.z >> 14) & 63u) - 32, sny = (int)((sv.z >> 20) & 63u) - 32, snz = (int)(sv.z >> 26) - 32;
+    if ((tag >> 6) != COOP_NO_SHIFT) { /* x - 0.0 == x bit for bit, so the unshifted case skips the arithmetic */
+      const int snx = (int)((tag >> 6) & 63u) - 32, sny = (int)((tag >> 12) & 63u) - 32, snz = (int)((tag >> 18) & 63u) - 32;
       tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
     }
-    const double *rec = ms.tri + (int64_t)(int)sv.x * DS_TRI_STRIDE;
+    const double *rec = ms.tri + (int64_t)(int)tri * DS_TRI_STRIDE;
     d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
     if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
   }
   if (lane == 0) W->n_surv = base;
   wave_sync();
   T_MARK(W, lane, 5);
-  { /* a smaller minimum than at the last flush invalidates the tie-break key of the earlier one */
+  { /* a smaller minimum than at the last flush: what was known about the old one is void */
     const unsigned long long cur = W->best_d[lane];
     if (cur != seen_d) {
-      W->best_key[lane] = ~0ULL;
+      W->best_tri[lane] = 0xffffffffu;
+      W->tie[lane] = 0;
       seen_d = cur;
     }
   }
   wave_sync();
-  const bool is_min = valid && d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner];
-  if (is_min) atomicMin(&W->best_key[owner], key); /* pass B: among equal d the earliest (visit, position) */
-  /* the owner reads the winner's triangle out of the key and fetches its precomputed unit normal in stage 4, and
-   * only if the hit lies within the step: most minima of a flush are beaten later or lie beyond the step's end */
+  if (valid && d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner]) {
+    /* pass B: the same triangle again (another cell, another subvoxel or image) is no tie - it IS the winner */
+    const unsigned old = atomicMin(&W->best_tri[owner], tri);
+    if (old != 0xffffffffu && old != tri) W->tie[owner] = 1;
+  }
   wave_sync();
   T_MARK(W, lane, 6);
 }
@@ -377,7 +340,6 @@ DSD bool walker_is_clear(const MeshDev &ms, const V3 &r) {
 DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, bool clear, const WalkParams &p,
                         const double *xs, const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
   const MeshDev &ms = p.mesh;
-  const int ny = ms.ny, nz = ms.nz;
   const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1; /* = xs[nx], ys[ny], zs[nz] */
   bool finished = false;
   bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
@@ -390,141 +352,94 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     act = false;
   }
   if (__ballot(act) == 0ULL) return finished;
-  if (lane == 0) {
-    W->n_surv = 0;
-    W->n_svq = 0;
-  }
+  if (lane == 0) W->n_surv = 0;
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
-#ifdef DSIM_STATS
-  W->filt[lane][0] = W->filt[lane][1] = W->filt[lane][2] = W->filt[lane][3] = 0xffffffffu;
+  W->best_tri[lane] = 0xffffffffu;
+#if COOP_DEDUPE
+  W->filt[lane][0] = W->filt[lane][1] = 0xffffffffu;
 #endif
-  W->best_key[lane] = ~0ULL;
   W->overflow[lane] = 0;
-  wave_sync();
+  W->tie[lane] = 0;
   T_MARK(W, lane, 1);
 #ifdef DSIM_TIMERS
   if (lane == 0) W->tacc[10] += 1;
 #endif
   bool serial = false;
-  /* ---- stage 1a: owners work out their cull box and list their subvoxels in range.  Box and ray
-   * stay in the owner's registers (cb0, r0, step: unchanged until stage 4); the other lanes read
+  /* ---- stage 1: owners work out their cull box and list the runs of fine cells their segment touches.  Box and
+   * ray stay in the owner's registers (cb0, r0, step: unchanged until stage 4); the other lanes read
    * them with __shfl, so every lane has to be active wherever a shuffle is executed. */
   CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  SubvoxelWalk sw = {0, 0, 0, 0, 0, 0};
+  FineRange fr = {0, 0, 0, 0, 0, 0};
+  int n_runs = 0;
   if (act) {
     iter_idx++;
     STAT_LANE(0);
     STAT_WAVE(0);
-    SubvoxelWalk sw;
-    segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0);
-    const long long nsub = (long long)max(0, sw.ulx - sw.llx) * max(0, sw.uly - sw.lly) * max(0, sw.ulz - sw.llz);
-    serial = nsub > 256 || !push_subvoxels(ms, sw, (int)nsub, W, lane);
+    segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0, fr);
+    n_runs = count_runs(ms, sw, fr);
+    serial = n_runs < 0;
+    n_runs = max(n_runs, 0);
   }
   T_MARK(W, lane, 2);
-  wave_sync();
-  /* ---- stage 1b: all lanes look the subvoxels up and list the micro-cells the cull box reaches */
-  int n_cellq = 0; /* cell tasks queued (wave-uniform; may exceed the capacity: the excess was not written) */
+  int n_runq; /* runs queued, the 64 first-run slots included (wave-uniform) */
   {
-    /* a counter read from LDS is the same in every lane, but only readfirstlane tells the compiler so: the queue
-     * loops then run on scalar compares and branches instead of exec-mask arithmetic, and their counters live
-     * in SGPRs */
-    const int n = __builtin_amdgcn_readfirstlane(min(W->n_svq, COOP_SVQ_CAP));
-    const uint2 *svq = coop_svq(W);
-    uint2 *cq = coop_cellq(W);
-    for (int first = 0; first < n; first += 64) {
-      const int idx = first + lane;
-      uint2 e = make_uint2(0xffffffffu, 0u);
-      if (idx < n) e = svq[idx];
-      const bool valid = e.x != 0xffffffffu;
-      const int owner = (int)(e.x & 63u);
-      const int x = (int)(e.y & 1023u), y = (int)((e.y >> 10) & 1023u), z = (int)(e.y >> 20);
-      const int sv = (x * ny + y) * nz + z;
-      int2 mg = make_int2(0, 0);
-      if (valid) {
-        STAT_LANE(1);
-        STAT_WAVE(1);
-        mg = ms.sv_micro[sv];
-      }
-      /* the owner's segment (7 floats through ds_bpermute); the box is rebuilt from it on this side */
-      CullBox cb = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, __shfl(cb0.mx, owner, 64), __shfl(cb0.my, owner, 64), __shfl(cb0.mz, owner, 64),
-                    __shfl(cb0.hx, owner, 64), __shfl(cb0.hy, owner, 64), __shfl(cb0.hz, owner, 64), __shfl(cb0.tau, owner, 64)};
-      box_from_segment(cb);
-      const bool has = mg.x != 0 && !ABLATE(1); /* not an empty subvoxel (or no task for this lane) */
-      if (has) {
-        STAT_LANE(2);
-        STAT_WAVE(2);
-      }
-      int a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, k = 1;
-      if (mg.x > 0 && !ABLATE(1)) {
-        if ((e.x >> 14) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
-          const int snx = (int)((e.x >> 14) & 63u) - 32, sny = (int)((e.x >> 20) & 63u) - 32, snz = (int)(e.x >> 26) - 32;
-          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
-        }
-        k = 1 << mg.y;
-        /* The cells the box reaches, in float32 and WIDENED: any superset of the exact cells of micro_cell() is
-         * valid (an extra cell only costs its records a look).  The float32 evaluation of (c - x0) * scale is off
-         * by < 0.5 ulp of the subvoxel origin times scale + a few ulps of the result, i.e. < 3e-7 k n_sv + 1e-6 k
-         * cells; the ranges are widened by dl >= 1e-3 + 5e-7 k n_sv cells on both sides. */
-        const float kf = (float)k;
-        const float dl = __builtin_fmaf(5e-7f * kf, (float)max(ms.nx, max(ms.ny, ms.nz)), 1e-3f);
-        const float sx = kf * (float)ms.inv_hx, sy = kf * (float)ms.inv_hy, sz = kf * (float)ms.inv_hz;
-        const float ox = (float)xs[x], oy = (float)ys[y], oz = (float)zs[z];
-        a0 = min(max((int)((cb.lox - ox) * sx - dl), 0), k - 1), a1 = min(max((int)((cb.hix - ox) * sx + dl), 0), k - 1);
-        b0 = min(max((int)((cb.loy - oy) * sy - dl), 0), k - 1), b1 = min(max((int)((cb.hiy - oy) * sy + dl), 0), k - 1);
-        c0 = min(max((int)((cb.loz - oz) * sz - dl), 0), k - 1), c1 = min(max((int)((cb.hiz - oz) * sz + dl), 0), k - 1);
-      }
-      /* queue slots from a prefix sum over the lanes (DPP; no LDS atomic) */
-      const int ncell = has ? (a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1) : 0;
-      const int incl = wave_inclusive_sum(ncell);
-      const int base = n_cellq + incl - ncell;
-      n_cellq += __builtin_amdgcn_readlane(incl, 63);
-      if (!has) continue;
-      if (base + ncell > COOP_CELLQ_CAP) {
-        /* queue full: neutralise the part of the reservation that lies inside the queue */
-        for (int j = base; j < COOP_CELLQ_CAP; j++) cq[j] = make_uint2(0xffffffffu, 0u);
-        W->overflow[owner] = 1;
-        continue;
-      }
-      if (mg.x < 0) { /* single-cell subvoxel: its record range is stored inline in sv_micro */
-        cq[base] = make_uint2(e.x, 0x80000000u | (unsigned)sv);
-        continue;
-      }
-      int j = base;
-      for (int a = a0; a <= a1; a++)
-        for (int b = b0; b <= b1; b++)
-          for (int c = c0; c <= c1; c++) cq[j++] = make_uint2(e.x, (unsigned)(mg.x + (a * k + b) * k + c));
+    const int extra_n = max(n_runs - 1, 0);
+    const int incl = wave_inclusive_sum(extra_n);
+    const int extra = 64 + incl - extra_n;
+    n_runq = 64 + __builtin_amdgcn_readlane(incl, 63);
+    if (n_runs > 0 && extra + extra_n > COOP_RUNQ_CAP) {
+      /* queue full: neutralise the part of the reservation that lies inside the queue */
+      for (int j = extra; j < COOP_RUNQ_CAP; j++) W->runq[j] = make_uint2(0xffffffffu, 0u);
+      serial = true;
+      n_runs = 0;
     }
+    if (n_runs > 0) {
+#ifdef DSIM_STATS
+      atomicAdd(&dsim_stats[1], (unsigned long long)((sw.ulx - sw.llx) * (sw.uly - sw.lly) * (sw.ulz - sw.llz)));
+      atomicAdd(&dsim_stats[2], (unsigned long long)n_runs);
+#endif
+      push_runs(ms, sw, fr, W, lane, extra);
+    } else {
+      W->runq[lane] = make_uint2(0xffffffffu, 0u);
+    }
+    n_runq = min(n_runq, COOP_RUNQ_CAP);
   }
   T_MARK(W, lane, 12);
   wave_sync();
-  /* ---- stages 1c, 2, 3 in rounds: the cell tasks are cut into 4-record items until the item queue
+  /* ---- stages 1c, 2, 3 in rounds: the runs are cut into 4-record items until the item queue
    * is nearly full, the items are drained into the survivor pool, the pool is flushed (fp64 tests,
-   * per-owner minimum) when it is half full - so no queue size limits the amount of work per pass */
+   * per-owner minimum) whenever it holds 64 - so no queue size limits the amount of work per pass */
   {
-    const int n_cells = min(n_cellq, COOP_CELLQ_CAP);
-    const uint2 *cq = coop_cellq(W);
-    uint2 *items = coop_items(W);
+    const int lk = ms.lk;
+    const unsigned cmask = (1u << (3 * lk)) - 1u;
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     int cursor = 0;
     int n_items = 0;        /* items waiting in the queue (wave-uniform) */
-    bool drain_all = false; /* the next cell does not fit behind the waiting items */
-    while (cursor < n_cells) {
-      /* -- 1c: up to 64 cell tasks per round, one per lane */
-      while (cursor < n_cells && n_items <= COOP_ITEM_CAP - 64) {
+    bool drain_all = false; /* the next run does not fit behind the waiting items */
+    while (cursor < n_runq) {
+      /* -- 1c: up to 64 runs per round, one per lane */
+      while (cursor < n_runq && n_items <= COOP_ITEM_CAP - 64) {
         const int idx = cursor + lane;
         uint2 e = make_uint2(0xffffffffu, 0u);
-        if (idx < n_cells) e = cq[idx];
-        int2 cr = make_int2(0, 0);
-        if (e.x != 0xffffffffu) {
-          const bool inl = (e.y & 0x80000000u) != 0;
-          const int2 *src = inl ? ms.sv_micro + (e.y & 0x7fffffffu) : ms.cell_range + e.y;
-          cr = *src;
-          if (inl) cr = make_int2(-cr.x - 1, -cr.x - 1 + cr.y);
-        }
+        if (idx < n_runq) e = W->runq[idx];
+        int first = 0, cnt = 0;
         if (e.x != 0xffffffffu) {
           STAT_LANE(5);
           STAT_WAVE(5);
+          int cell = (int)e.y;
+          bool some = true;
+          if (lk > 0) {
+            const int base = ms.sv_base[e.y >> (3 * lk)];
+            some = base >= 0;
+            cell = base + (int)(e.y & cmask);
+          }
+          if (some && !ABLATE(2)) {
+            const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
+            first = (int)r0i;
+            cnt = (int)(r1i - r0i);
+          }
         }
-        const int cnt = ABLATE(2) ? 0 : max(0, cr.y - cr.x);
         const int nb = (cnt + 3) >> 2;
         if (nb > 0) {
           STAT_LANE(3);
@@ -538,16 +453,17 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             drain_all = true;
             break;
           }
-          /* a single cell with more records than the whole queue holds: its owner works serially */
+          /* a single run with more records than the whole queue holds: its owner works serially */
           if (lane == 0) W->overflow[(int)(e.x & 63u)] = 1;
           cursor += 1;
           continue;
         }
         if (lane < n_take) {
           const int base = n_items + incl - nb;
+          const unsigned tag = e.x & 0xffffffu;
           for (int j = 0; j < nb; j++) {
             const int left = cnt - 4 * j;
-            items[base + j] = make_uint2((unsigned)(cr.x + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), e.x);
+            W->items[base + j] = make_uint2((unsigned)(first + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), tag);
           }
         }
         n_items += __builtin_amdgcn_readlane(incl, n_take - 1);
@@ -556,9 +472,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       }
       T_MARK(W, lane, 13);
       /* -- 2: all lanes drain the item queue: float32 AABB + plane culling against the owner's box.
-       * While more cells are coming only full trips of 64 items are drained (the tail of the queue);
+       * While more runs are coming only full trips of 64 items are drained (the tail of the queue);
        * the remainder waits at the head for the next round */
-      const int start = (cursor >= n_cells || drain_all) ? 0 : (n_items & 63);
+      const int start = (cursor >= n_runq || drain_all) ? 0 : (n_items & 63);
       drain_all = false;
       if (start == n_items) continue;
       wave_sync();
@@ -566,7 +482,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const int idx = first + lane;
         const bool valid = idx < n_items;
         uint2 it = make_uint2(0u, 0u);
-        if (valid) it = items[idx];
+        if (valid) it = W->items[idx];
         const int owner = (int)(it.y & 63u);
         CullBox cb;
         cb.mx = __shfl(cb0.mx, owner, 64), cb.my = __shfl(cb0.my, owner, 64), cb.mz = __shfl(cb0.mz, owner, 64);
@@ -574,50 +490,60 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         cb.tau = __shfl(cb0.tau, owner, 64);
         box_from_segment(cb);
         if (valid) {
-        STAT_LANE(4);
-        STAT_WAVE(4);
-        const int first_rec = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
-        if ((it.y >> 14) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
-          const int snx = (int)((it.y >> 14) & 63u) - 32, sny = (int)((it.y >> 20) & 63u) - 32, snz = (int)(it.y >> 26) - 32;
-          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
-        }
-        float4 q0[4], q1[4], q2[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
-          q0[u] = ms.mrec[3 * j];
-          q1[u] = ms.mrec[3 * j + 1];
-          q2[u] = ms.mrec[3 * j + 2];
-        }
-        /* the four tests without a branch between them (the plane test used to sit behind the box test, but
-         * with 64 lanes x 4 records somebody always passes the box, so the branch only cost mask juggling);
-         * one LDS atomic per lane reserves the slots of all its survivors */
-        unsigned alive = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) alive |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
-        alive &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
-        if (ABLATE(3) || ABLATE(4)) alive = 0;
-        if (alive) {
-          int slot = atomicAdd(&W->n_surv, (int)__builtin_popcount(alive));
+          STAT_LANE(4);
+          STAT_WAVE(4);
+          const int first_rec = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
+          const bool shifted = (it.y >> 6) != COOP_NO_SHIFT;
+          if (shifted) { /* periodic image: move the box into its frame */
+            const int snx = (int)((it.y >> 6) & 63u) - 32, sny = (int)((it.y >> 12) & 63u) - 32, snz = (int)((it.y >> 18) & 63u) - 32;
+            cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+          }
+          float4 q0[4], q1[4], q2[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            if (!(alive >> u & 1u)) continue;
-#ifdef DSIM_STATS
-            {
-              const unsigned pos_ = (unsigned)__float_as_int(q2[u].w);
-              const unsigned prev_ = atomicExch(&W->filt[owner][(pos_ ^ (pos_ >> 2)) & 3u], pos_);
-              if (prev_ == pos_) STAT_LANE(7); /* the same list entry of the same owner survived from another cell */
-            }
-#endif
-            if (slot < COOP_SURV_CAP) {
-              W->surv_tri[slot] = (unsigned)__float_as_int(q2[u].z);
-              W->surv_pos[slot] = (unsigned)__float_as_int(q2[u].w);
-              W->surv_tag[slot] = it.y;
-            } else
-              W->overflow[owner] = 1;
-            slot++;
+            const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
+            q0[u] = ms.mrec[3 * j];
+            q1[u] = ms.mrec[3 * j + 1];
+            q2[u] = ms.mrec[3 * j + 2];
           }
-        }
+          /* the four tests without a branch between them (with 64 lanes x 4 records somebody always passes the
+           * box, so a branch only costs mask juggling) */
+          unsigned alive = 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) alive |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
+          alive &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
+          if (ABLATE(3) || ABLATE(4)) alive = 0;
+#if COOP_DEDUPE
+          /* A triangle reaches the pool through every cell it shares with the segment's box (17 % of the survivors on
+           * the neuron were repeats): the owner's last survivors are remembered in a 2-way hashed table and a repeat
+           * is dropped - the fp64 test of the same triangle and ray returns the same d, and the first copy is already
+           * in the pool or has been tested.  Only for the unshifted image (the table holds the triangle alone); of
+           * two lanes that offer the same triangle at once exactly one sees the other's entry. */
+          if (alive && !shifted) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (!(alive >> u & 1u)) continue;
+              const unsigned t = (unsigned)__float_as_int(q2[u].z);
+              if (atomicExch(&W->filt[owner][(t ^ (t >> 1)) & 1u], t) == t) {
+                alive &= ~(1u << u);
+                STAT_LANE(7);
+              }
+            }
+          }
+#endif
+          if (alive) { /* one LDS atomic per lane reserves the slots of all its survivors */
+            int slot = atomicAdd(&W->n_surv, (int)__builtin_popcount(alive));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (!(alive >> u & 1u)) continue;
+              if (slot < COOP_SURV_CAP) {
+                W->surv_tri[slot] = (unsigned)__float_as_int(q2[u].z);
+                W->surv_tag[slot] = it.y;
+              } else
+                W->overflow[owner] = 1;
+              slot++;
+            }
+          }
         }
         T_MARK(W, lane, 4);
         /* a trip adds 15 survivors on average and 256 at most: whenever the pool holds 64, its last
@@ -636,32 +562,31 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   /* ---- stage 4: resolve (simulations.py:986-997) */
   if (act) {
     double d = DS_INF;
-    V3 n = {0, 0, 0};
-    if (serial || W->overflow[lane]) {
-      /* this walker's work did not fit the queues: its whole iteration again, by its own lane */
-      STAT_LANE(9);
-      STAT_WAVE(9);
-      BestHit best = {DS_INF, 0x7fffffff, 0x7fffffff, 0, false, {0, 0, 0}};
-      SubvoxelWalk sw; /* recomputed rather than kept in registers through the drain stages */
-      CullBox cbx;
-      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cbx);
-      iteration_serial(ms, sw, r0, step, xs, ys, zs, best);
-      d = best.d;
-      if (d <= step_l) {
-        const double *rec = ms.tri + (int64_t)best.tri * DS_TRI_STRIDE;
-        n = load_v3(rec + 9);
-      }
-    } else {
+    int tri = 0;
+    bool redo = serial || W->overflow[lane];
+    if (!redo) {
       const unsigned long long bd = W->best_d[lane];
       if (bd != 0x7ff0000000000000ULL) {
         d = __longlong_as_double((long long)bd);
-        if (d <= step_l) n = load_v3(ms.tri + (int64_t)(W->best_key[lane] & 0xffffffULL) * DS_TRI_STRIDE + 9);
+        tri = (int)W->best_tri[lane];
+        redo = d <= step_l && W->tie[lane]; /* the reference's visiting order decides between equal distances */
       }
+    }
+    if (redo) {
+      /* this walker's whole iteration again, by its own lane, exactly as the reference does it */
+      STAT_LANE(9);
+      STAT_WAVE(9);
+      BestHit best = {DS_INF, 0};
+      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0, fr); /* recomputed rather than kept in registers through the drain stages */
+      iteration_serial(ms, sw, r0, step, xs, ys, zs, best);
+      d = best.d;
+      tri = best.tri;
     }
     T_MARK(W, lane, 7);
     if (d > step_l) {
       finished = true; /* check_intersection = False */
     } else {
+      V3 n = load_v3(ms.tri + (int64_t)tri * DS_TRI_STRIDE + 9);
       const bool reflect = p.perm_prob < rng_uniform_f64(rng);
       if (reflect)
         reflection(r0, step, d, n, p.eps);

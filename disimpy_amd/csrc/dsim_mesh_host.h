@@ -45,7 +45,9 @@ struct DevMesh {
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
   float4 *mrec = nullptr;
-  int2 *sv_micro = nullptr, *cell_range = nullptr;
+  int32_t *sv_base = nullptr;
+  uint32_t *cell_start = nullptr;
+  int lk = 0; /* log2 of the fine cells per subvoxel and axis */
   int32_t *clear_idx = nullptr;
   uint32_t *clear_bits = nullptr;
   int clear_lf = 0;
@@ -55,7 +57,11 @@ struct DevMesh {
   double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0};
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; /* first and last boundary of every axis */
   bool set = false;
-  bool coop_ok = false; /* fewer than 2^24 triangles and list entries */
+  /* the subvoxel boundaries are what the reference builds - np.linspace(0, L, n + 1) on every axis (substrates.py:506-508) -
+   * to within 1e-6 of a subvoxel width: the cooperative traversal's float32 shortcut for the subvoxel ranges, its
+   * arithmetic fine-cell coordinates and the clearance map assume it.  Any other grid handed in through the C ABI is
+   * walked by the per-lane traversal, which checks every guess against the boundary values themselves. */
+  bool coop_ok = false;
 };
 
 static void free_mesh(DevMesh &m) {
@@ -63,8 +69,8 @@ static void free_mesh(DevMesh &m) {
   if (m.sv_range) (void)hipFree(m.sv_range);
   if (m.tri_idx) (void)hipFree(m.tri_idx);
   if (m.mrec) (void)hipFree(m.mrec);
-  if (m.sv_micro) (void)hipFree(m.sv_micro);
-  if (m.cell_range) (void)hipFree(m.cell_range);
+  if (m.sv_base) (void)hipFree(m.sv_base);
+  if (m.cell_start) (void)hipFree(m.cell_start);
   if (m.clear_idx) (void)hipFree(m.clear_idx);
   if (m.clear_bits) (void)hipFree(m.clear_bits);
   if (m.bounds) (void)hipFree(m.bounds);
@@ -377,16 +383,19 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
     refs[i] = (int32_t)triangle_indices[i];
   }
-  /* Micro-grids.  The reference's candidate set of a subvoxel is its whole list
-   * (up to 88 triangles per 4.3 um subvoxel on the neuron, several subvoxels per
-   * step), and a wavefront pays for its worst lane.  Every reference subvoxel
-   * with more than 8 references is therefore cut into k^3 micro-cells (k = 2, 4,
-   * 8); cell c holds the references of THIS subvoxel whose float32 AABB (rounded
-   * outward, clamped into the subvoxel) reaches c.  A query visits the cells
-   * reached by the segment's cull box (same clamped, monotone cell map), i.e. a
-   * subset of the reference's list that still contains every triangle whose AABB
-   * meets the cull box - the same exactness argument as make_cull_box(). Each
-   * 32-byte record = float32 AABB + triangle index + CSR position (tie order). */
+  /* Fine grid.  The reference's candidate set of a subvoxel is its whole list (up to 88 triangles per 4.3 um
+   * subvoxel on the neuron), and a wavefront pays for its worst lane.  Every NON-EMPTY reference subvoxel is
+   * therefore cut into k^3 cells, k = 2^lk the same for the whole mesh, so that a walker can name the cells its
+   * segment touches by arithmetic alone (global fine coordinate = subvoxel * k + cell; no look-up per subvoxel
+   * before the cells are known).  Cell c of subvoxel s lists the references OF s whose triangle reaches c; the
+   * border cells of a subvoxel extend to infinity outwards (the query clamps its cell range into the subvoxel), so
+   * whatever the reference lists in s is found through s - the exactness argument never leans on the reference's
+   * index being geometrically complete.  48-byte records {AABB of the triangle's part inside the cell, supporting
+   * plane in float32, triangle, position in the reference's list}; the cells of one subvoxel are stored z-fastest
+   * and their records back to back, so a run of cells along z is ONE contiguous range of records:
+   *     sv_base[s]           first cell of subvoxel s in cell_start, -1 for an empty subvoxel
+   *                          (lk == 0: not used, cell_start is indexed by s itself)
+   *     cell_start[c .. c+r] records of the r cells c .. c+r-1: [cell_start[c], cell_start[c+r]) of mrec */
   double inv_h3[3];
   {
     const double *b3[3] = {xs, ys, zs};
@@ -398,8 +407,11 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   double sub_min = 1e300; /* smallest subvoxel edge */
   for (int k = 0; k < 3; k++)
     if (inv_h3[k] > 0) sub_min = std::min(sub_min, 1.0 / inv_h3[k]);
-  /* thresholds of the micro-grid (tuned on the neuron and the packed cylinders); DSIM_MICRO="t1,t2,t3,t4,min_cell"
-   * overrides them for tuning runs - results never depend on them */
+  /* k by the density of the lists a walker meets (the mean list length seen from a list entry) with the thresholds
+   * tuned in round 2 on the neuron and the packed cylinders (more than 2 / 4 / 16 entries: k = 2 / 4 / 8), but no
+   * cell smaller than `min_cell` step lengths (a segment that spans several cells per axis multiplies the runs)
+   * and no more than 2^30 cells in all.  DSIM_MICRO="t1,t2,t3,t4,min_cell" overrides thresholds and min_cell in
+   * tuning runs - results never depend on them. */
   int micro_t[4] = {2, 4, 16, 1 << 30};
   double micro_min_cell = 1.5;
   if (const char *env = getenv("DSIM_MICRO")) {
@@ -410,28 +422,33 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       micro_min_cell = m;
     }
   }
-  std::vector<int2> sv_micro((size_t)n_sub);
-  std::vector<int2> cell_range;
+  int64_t n_nonempty = 0;
+  double sum_n = 0, sum_n2 = 0;
+  for (int64_t s = 0; s < n_sub; s++) {
+    const double n_s = ranges[s].y - ranges[s].x;
+    if (n_s <= 0) continue;
+    n_nonempty++;
+    sum_n += n_s;
+    sum_n2 += n_s * n_s;
+  }
+  const double met = sum_n > 0 ? sum_n2 / sum_n : 0.0;
+  int lk = met <= micro_t[0] ? 0 : (met <= micro_t[1] ? 1 : (met <= micro_t[2] ? 2 : (met <= micro_t[3] ? 3 : 4)));
+  while (lk > 0 && sub_min / (double)(1 << lk) < micro_min_cell * step_l) lk--;
+  while (lk > 0 && ((double)n_nonempty * (double)(1 << (3 * lk)) > (double)(1 << 30) || (double)n_sub * (double)(1 << (3 * lk)) >= 4294967296.0)) lk--;
+  const int k = 1 << lk;
+  std::vector<int32_t> sv_base((size_t)(lk > 0 ? n_sub : 1), -1);
+  std::vector<uint32_t> cell_start;
   std::vector<float4> mrec;
-  cell_range.push_back(make_int2(0, 0)); /* cell 0: shared by all empty subvoxels */
+  cell_start.reserve((size_t)(lk > 0 ? n_nonempty * k * k * k : n_sub) + 1);
   {
     std::vector<std::vector<int32_t>> cells;
     std::vector<float> lo3, hi3;
     for (int64_t s = 0; s < n_sub; s++) {
       const int begin = ranges[s].x, end = ranges[s].y, n_s = end - begin;
       if (n_s <= 0) {
-        sv_micro[s] = make_int2(0, 0);
+        if (lk == 0) cell_start.push_back((uint32_t)(mrec.size() / 3)); /* dense over the subvoxels: an empty range */
         continue;
       }
-      /* k^3 micro-cells (k = 2 / 4 / 8) for more than 2 / 4 / 16 references - round 2, with the cheaper
-       * branch-free record test: 5 % faster on the refined neuron than round 1's 4 / 16 / 64, itself 4.5 %
-       * faster than 8 / 32 / 128; {1,4,12}, {1,3,12}, {2,6,24} and k = 16 for the densest subvoxels are all
-       * within 0.5 % of it - but no cell smaller than 1.5 step lengths: a query box that spans
-       * several cells per axis multiplies the cell tasks (packed cylinders with 0.4 um
-       * subvoxels: 3.3e9 instead of 7.3e9 spin-steps/s with k = 2; 2.0 step lengths cost the neuron 5 %) */
-      int lk = n_s <= micro_t[0] ? 0 : (n_s <= micro_t[1] ? 1 : (n_s <= micro_t[2] ? 2 : (n_s <= micro_t[3] ? 3 : 4)));
-      while (lk > 0 && sub_min / (double)(1 << lk) < micro_min_cell * step_l) lk--;
-      const int k = 1 << lk;
       const int64_t sx = s / (n_sv[1] * n_sv[2]), sy = (s / n_sv[2]) % n_sv[1], sz = s % n_sv[2];
       const double org[3] = {xs[sx], ys[sy], zs[sz]};
       const double scale[3] = {(double)k * inv_h3[0], (double)k * inv_h3[1], (double)k * inv_h3[2]};
@@ -461,12 +478,11 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
               cells[((size_t)a * k + b) * k + c].push_back(i);
             }
       }
-      sv_micro[s] = make_int2((int)cell_range.size(), lk);
-      if (lk == 0) sv_micro[s] = make_int2(-((int)(mrec.size() / 3) + 1), n_s); /* single cell: range inline */
+      if (lk > 0) sv_base[s] = (int32_t)cell_start.size();
       for (size_t ci = 0; ci < cells.size(); ci++) {
         auto &cl = cells[ci];
         const int abc[3] = {(int)(ci / ((size_t)k * k)), (int)((ci / k) % k), (int)(ci % k)};
-        int start = (int)(mrec.size() / 3);
+        cell_start.push_back((uint32_t)(mrec.size() / 3));
         for (int32_t i : cl) {
           float lo[3], hi[3];
           for (int ax = 0; ax < 3; ax++) lo[ax] = lo3[(size_t)(i - begin) * 3 + ax], hi[ax] = hi3[(size_t)(i - begin) * 3 + ax];
@@ -502,9 +518,10 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
           mrec.push_back(make_float4(hi[1], hi[2], fx, fy));
           mrec.push_back(make_float4(fz, fc, idx_bits, pos_bits));
         }
-        cell_range.push_back(make_int2(start, (int)(mrec.size() / 3)));
       }
     }
+    if (mrec.size() / 3 >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
+    cell_start.push_back((uint32_t)(mrec.size() / 3)); /* end of the last cell */
     if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
   }
   std::vector<double> bounds;
@@ -528,11 +545,12 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&dm.mrec, mrec.size() * sizeof(float4)));
-  HIP_TRY(hipMalloc(&dm.sv_micro, sv_micro.size() * sizeof(int2)));
-  HIP_TRY(hipMalloc(&dm.cell_range, cell_range.size() * sizeof(int2)));
+  HIP_TRY(hipMalloc(&dm.sv_base, sv_base.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&dm.cell_start, cell_start.size() * sizeof(uint32_t)));
   HIP_TRY(hipMemcpyAsync(dm.mrec, mrec.data(), mrec.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.sv_micro, sv_micro.data(), sv_micro.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.cell_range, cell_range.data(), cell_range.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.sv_base, sv_base.data(), sv_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  dm.lk = lk;
   HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
@@ -551,7 +569,13 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     dm.hi[k] = b3[k][n_sv[k]];
   }
   dm.set = true;
-  dm.coop_ok = n_faces < (1 << 24) && n_refs < (1 << 24);
+  dm.coop_ok = true;
+  for (int k = 0; k < 3; k++) {
+    const double L = b3[k][n_sv[k]] - b3[k][0], h = L / (double)n_sv[k];
+    if (!(L > 0) || !std::isfinite(L) || b3[k][0] != 0.0) dm.coop_ok = false;
+    for (int64_t i = 0; i <= n_sv[k] && dm.coop_ok; i++)
+      if (!(std::fabs(b3[k][i] - (double)i * h) <= 1e-6 * h)) dm.coop_ok = false;
+  }
   return DSIM_OK;
 }
 
@@ -561,8 +585,9 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
   m.mrec = dm.mrec;
-  m.sv_micro = dm.sv_micro;
-  m.cell_range = dm.cell_range;
+  m.sv_base = dm.sv_base;
+  m.cell_start = dm.cell_start;
+  m.lk = dm.lk;
   m.bounds = dm.bounds;
   m.clear_idx = dm.clear_idx;
   m.clear_bits = dm.clear_bits;
