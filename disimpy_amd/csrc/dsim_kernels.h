@@ -466,12 +466,30 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
   r0.z = __builtin_fma(step.z, step_l, r0.z);
 }
 
+/* The launch parameters, read afresh.  A kernel argument struct of ~100 dwords that is read through its by-value
+ * parameter is fetched into SGPRs once and kept there for the whole kernel; the cooperative mesh kernel, whose pass
+ * loop needs most of the scalar file for itself, then spills them through VGPR lanes (v_writelane / v_readlane are
+ * VALU instructions in a VALU-bound kernel: round 2 shipped with 124 spilled SGPRs).  With KA = 1 the kernel instead
+ * re-reads what a stage needs from the kernarg segment (scalar loads out of the constant cache) through a pointer the
+ * compiler cannot see through, so no value lives longer than the stage that uses it.  KA = 0 (every other kernel, and
+ * the test wrappers): the by-value parameter as it is.  WalkParams must be the kernel's first and only argument. */
+template <int KA>
+DSD const WalkParams &fresh_params(const WalkParams &p) {
+  if (KA) {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const WalkParams *)k;
+  }
+  return p;
+}
+
 #include "dsim_mesh_coop.h"
 
 /* ---- the fused kernel --------------------------------------------------------- */
 
-template <int GEOM, int MB, int GSRC, int COOP, int TRAJ = 0>
-DSD void walk_body(const WalkParams &p) {
+template <int GEOM, int MB, int GSRC, int COOP, int TRAJ = 0, int KA = 0>
+DSD void walk_body(const WalkParams &p_arg) {
+  const WalkParams &p = fresh_params<KA>(p_arg);
   extern __shared__ double lds[];
   double *log_tab = lds;                           /* 128 doubles                     */
   double *cos_tab = lds + DS_LOG_TABLE_DOUBLES;    /* 514 doubles                     */
@@ -557,6 +575,7 @@ DSD void walk_body(const WalkParams &p) {
       double sl = 0;
       int64_t iter_idx = 0;
       for (int passes = 0;; passes++) {
+        const WalkParams &p = fresh_params<KA>(p_arg); /* nothing of the launch parameters stays in SGPRs across passes */
         const bool want = live && k_lane < kt;
         const bool may_start = p.tcur == nullptr || passes < p.iter_budget; /* wave-uniform */
         if (__ballot(want && (in_step || may_start)) == 0ULL) break;
@@ -568,7 +587,7 @@ DSD void walk_body(const WalkParams &p) {
           in_step = true;
         }
         T_MARK(coop, lane, 0);
-        const bool finished = coop_iteration(r, step, sl, iter_idx, in_step, clear, p, xs, ys, zs, rng, coop, lane);
+        const bool finished = coop_iteration<KA>(r, step, sl, iter_idx, in_step, clear, p, xs, ys, zs, rng, coop, lane);
         clear = false; /* only the first pass of a step starts a full step length away from its start */
         if (in_step && finished) {
           if (iter_idx >= p.max_iter) exc = true; /* simulations.py:999-1002 */
@@ -603,7 +622,7 @@ DSD void walk_body(const WalkParams &p) {
         }
         T_MARK(coop, lane, 9);
       }
-      if (p.tcur != nullptr && live) p.tcur[i] = t0 + k_lane;
+      if (fresh_params<KA>(p_arg).tcur != nullptr && live) fresh_params<KA>(p_arg).tcur[i] = t0 + k_lane;
 #ifdef DSIM_TIMERS
       if (lane == 0)
         for (int q = 0; q < 16; q++) atomicAdd(&dsim_timers[q], coop->tacc[q]);
@@ -655,6 +674,7 @@ DSD void walk_body(const WalkParams &p) {
   }
 
   if (live) {
+    const WalkParams &p = fresh_params<KA>(p_arg);
 #pragma unroll
     for (int m = 0; m < MB; m++)
       if (m < p.mc) p.phase[(int64_t)(p.m0 + m) * p.phase_stride + i] = ph[m];
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
  * and every resident wavefront hides some of its latency (measured: +10..14 % over three). */
 template <int MB, int GSRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void walk_kernel_coop4(const WalkParams p) {
-  walk_body<GEOM_MESH, MB, GSRC, 1>(p);
+  walk_body<GEOM_MESH, MB, GSRC, 1, 0, 1>(p);
 }
 
 /* 32 measurements in the kernel and the positions of every step recorded in p.traj: the first pass
@@ -693,7 +713,7 @@ __global__ __launch_bounds__(256) void walk_kernel_traj32(const WalkParams p) {
 /* the same, recording the position after every step in p.traj (phases are then accumulated by
  * phase_from_traj_kernel: mesh substrates with more than two measurements) */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void walk_kernel_coop4_traj(const WalkParams p) {
-  walk_body<GEOM_MESH, 1, 1, 1, 1>(p);
+  walk_body<GEOM_MESH, 1, 1, 1, 1, 1>(p);
 }
 
 /* Phase accumulation from recorded positions: phases[m, i] += GAMMA*dt * g[m, t] . r_i(t) for the

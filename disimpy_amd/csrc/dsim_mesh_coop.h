@@ -61,13 +61,16 @@
 #define COOP_DEDUPE 1
 #endif
 
-/* Per-wavefront scratch in LDS (7.4 KB).  The owners' cull boxes and rays are NOT here: they
+/* Per-wavefront scratch in LDS (7.9 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
  * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
   unsigned long long best_d[64];   /* smallest positive d (bit pattern orders like the value)                 0.5 KB */
   unsigned best_tri[64];           /* a triangle that attains it (the smallest index among those seen)        0.25 KB */
-  uint2 runq[COOP_RUNQ_CAP];       /* runs {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell}  2.5 KB */
+  uint2 first[64];                 /* every owner's first run {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell} */
+  unsigned more[COOP_RUNQ_CAP - 64]; /* the other runs, by name only: owner | number of the run << 6              1.5 KB */
+  int4 plan_a[64];                 /* what the runs of an owner are numbered over (RunPlan): a0, b0, c0, c1 ...          */
+  int2 plan_b[64];                 /*   ... first z unit, columns in y | z units << 8                              1.5 KB */
   uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 30, owner | shifts << 6} (1c -> 2)  2.0 KB */
   unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
   unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6                                                   1.0 KB */
@@ -216,18 +219,6 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
   fine_limits(tn2, tx2, q2, sw.llz, sw.ulz, ms.lk, fr.c0, fr.c1);
 }
 
-/* number of runs of the pass (0: the reference's range is empty, nothing is visited), or -1 when the walker cannot be
- * queued: image shifts must fit 6 bits each, and no more than COOP_MAX_RUNS runs per owner */
-DSD int count_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f) {
-  if (w.ulx <= w.llx || w.uly <= w.lly || w.ulz <= w.llz) return 0;
-  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
-  if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return -1;
-  const int na = f.a1 - f.a0 + 1, nb = f.b1 - f.b0 + 1, nc = w.ulz - w.llz;
-  if (na > COOP_MAX_RUNS || nb > COOP_MAX_RUNS || nc > COOP_MAX_RUNS) return -1;
-  const int n = na * nb * nc;
-  return n > COOP_MAX_RUNS ? -1 : n;
-}
-
 /* wrapped subvoxel coordinate and image number of an absolute subvoxel coordinate */
 DSD void wrap_subvoxel(int s, int n, int &x, int &sn) {
   x = s, sn = 0;
@@ -237,30 +228,69 @@ DSD void wrap_subvoxel(int s, int n, int &x, int &sn) {
   }
 }
 
-/* Stage 1: the owner writes its runs - for every (x, y) fine column of its range and every subvoxel along z one run
- * of cells - into the run queue: the first into slot `lane`, the others from slot `extra` on. */
-DSD void push_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, CoopWave *W, int lane, int extra) {
-  const int lk = ms.lk, k = 1 << lk, km = k - 1;
-  int slot = lane;
-  for (int a = f.a0; a <= f.a1; a++) {
-    int x, snx;
-    wrap_subvoxel(a >> lk, ms.nx, x, snx);
-    for (int b = f.b0; b <= f.b1; b++) {
-      int y, sny;
-      wrap_subvoxel(b >> lk, ms.ny, y, sny);
-      const unsigned col = (unsigned)((((a & km) << lk) | (b & km)) << lk);
-      for (int zi = w.llz; zi < w.ulz; zi++) {
-        int z, snz;
-        wrap_subvoxel(zi, ms.nz, z, snz);
-        const int cs = max(f.c0, zi * k), ce = min(f.c1, zi * k + km);
-        const unsigned sv = (unsigned)((x * ms.ny + y) * ms.nz + z);
-        W->runq[slot] = make_uint2((unsigned)lane | ((unsigned)(snx + 32) << 6) | ((unsigned)(sny + 32) << 12) | ((unsigned)(snz + 32) << 18) |
-                                       ((unsigned)(ce - cs) << 24),
-                                   (sv << (3 * lk)) + (col | (unsigned)(cs & km)));
-        slot = slot == lane ? extra : slot + 1;
-      }
-    }
+/* The runs of a pass.  A run is a stretch of fine cells along z whose records are contiguous in mrec: inside one
+ * subvoxel (lk > 0: its k cells of one (x, y) fine column) or, when the subvoxels themselves are the cells (lk == 0),
+ * inside one periodic image of the z axis (cell_start is indexed by the subvoxel, z-fastest).  The "z unit" is that
+ * stretch - a subvoxel or an image.  The runs of an owner are numbered j = (ia * nb + ib) * nc + iz over its na x nb
+ * fine columns and nc z units; any lane can work out run j from the plan alone. */
+struct RunPlan {
+  int a0, b0, c0, c1; /* first fine column, fine z range */
+  int zu0;            /* first z unit */
+  int nb, nc;         /* columns along y, z units */
+};
+
+/* number of runs of the pass (0: the reference's range is empty, nothing is visited), or -1 when the walker cannot be
+ * queued: image shifts must fit 6 bits each, a run holds at most 16 cells, and no more than COOP_MAX_RUNS runs */
+DSD int plan_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, RunPlan &rp) {
+  if (w.ulx <= w.llx || w.uly <= w.lly || w.ulz <= w.llz) return 0;
+  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+  if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return -1;
+  int zu1;
+  if (ms.lk > 0) {
+    rp.zu0 = w.llz, zu1 = w.ulz - 1;
+  } else {
+    if (w.ulz - w.llz > 16) return -1;
+    int z;
+    wrap_subvoxel(w.llz, nz, z, rp.zu0);
+    wrap_subvoxel(w.ulz - 1, nz, z, zu1);
   }
+  const int na = f.a1 - f.a0 + 1;
+  rp.a0 = f.a0, rp.b0 = f.b0, rp.c0 = f.c0, rp.c1 = f.c1;
+  rp.nb = f.b1 - f.b0 + 1, rp.nc = zu1 - rp.zu0 + 1;
+  if (na > COOP_MAX_RUNS || rp.nb > COOP_MAX_RUNS || rp.nc > COOP_MAX_RUNS) return -1;
+  const int n = na * rp.nb * rp.nc;
+  return n > COOP_MAX_RUNS ? -1 : n;
+}
+
+/* run j of an owner's plan as a queue entry {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell} */
+DSD uint2 make_run(const MeshDev &ms, int owner, const RunPlan &rp, int j) {
+  const int lk = ms.lk, k = 1 << lk, km = k - 1;
+  int ia = 0, ib = 0, iz = j;
+  if (j > 0) { /* j < 64: (j + 1/2) / n is at least 1/128 away from every integer, the reciprocal is good to 1e-6 */
+    const int bc = rp.nb * rp.nc;
+    ia = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)bc));
+    const int rem = j - ia * bc;
+    ib = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)rp.nc));
+    iz = rem - ib * rp.nc;
+  }
+  const int a = rp.a0 + ia, b = rp.b0 + ib, zu = rp.zu0 + iz;
+  int x, snx, y, sny, z, snz, cs, ce;
+  wrap_subvoxel(a >> lk, ms.nx, x, snx);
+  wrap_subvoxel(b >> lk, ms.ny, y, sny);
+  if (lk > 0) {
+    wrap_subvoxel(zu, ms.nz, z, snz);
+    cs = max(rp.c0, zu * k), ce = min(rp.c1, zu * k + km);
+  } else {
+    snz = zu;
+    const int lo = zu * ms.nz;
+    cs = max(rp.c0, lo), ce = min(rp.c1, lo + ms.nz - 1);
+    z = cs - lo;
+  }
+  const unsigned sv = (unsigned)((x * ms.ny + y) * ms.nz + z);
+  const unsigned cell = (unsigned)(((((a & km) << lk) | (b & km)) << lk) | (cs & km));
+  return make_uint2((unsigned)owner | ((unsigned)(snx + 32) << 6) | ((unsigned)(sny + 32) << 12) | ((unsigned)(snz + 32) << 18) |
+                        ((unsigned)(ce - cs) << 24),
+                    (sv << (3 * lk)) + cell);
 }
 
 /* Stage 3: one trip of fp64 tests over the survivors [base, base + count) of the pool, count <= 64:
@@ -337,10 +367,10 @@ DSD bool walker_is_clear(const MeshDev &ms, const V3 &r) {
  * no longer holds).  The caller lets every lane run through its own time steps at its own pace
  * (a wavefront then needs about mean-iterations-per-step passes per step, not the maximum over
  * its 64 lanes). */
-DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, bool clear, const WalkParams &p,
+template <int KA>
+DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, bool clear, const WalkParams &p_arg,
                         const double *xs, const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
-  const MeshDev &ms = p.mesh;
-  const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1; /* = xs[nx], ys[ny], zs[nz] */
+  const WalkParams &p = fresh_params<KA>(p_arg);
   bool finished = false;
   bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
   if (in_step && !act) finished = true; /* while-condition false on entry */
@@ -369,40 +399,48 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
    * ray stay in the owner's registers (cb0, r0, step: unchanged until stage 4); the other lanes read
    * them with __shfl, so every lane has to be active wherever a shuffle is executed. */
   CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  SubvoxelWalk sw = {0, 0, 0, 0, 0, 0};
-  FineRange fr = {0, 0, 0, 0, 0, 0};
   int n_runs = 0;
+  RunPlan rp = {0, 0, 0, 0, 0, 1, 1};
+  const MeshDev &ms = p.mesh;
   if (act) {
     iter_idx++;
     STAT_LANE(0);
     STAT_WAVE(0);
+    SubvoxelWalk sw;
+    FineRange fr;
     segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0, fr);
-    n_runs = count_runs(ms, sw, fr);
+    n_runs = plan_runs(ms, sw, fr, rp);
     serial = n_runs < 0;
     n_runs = max(n_runs, 0);
+#ifdef DSIM_STATS
+    if (n_runs > 0) atomicAdd(&dsim_stats[1], (unsigned long long)((sw.ulx - sw.llx) * (sw.uly - sw.lly) * (sw.ulz - sw.llz)));
+    atomicAdd(&dsim_stats[2], (unsigned long long)n_runs);
+#endif
   }
   T_MARK(W, lane, 2);
   int n_runq; /* runs queued, the 64 first-run slots included (wave-uniform) */
   {
+    /* the first run goes, complete, into the slot of the owner's own lane; the others are only NAMED in the queue
+     * (a loop of one 4-byte store per run) and worked out from the owner's plan by whichever lane takes them in
+     * stage 1c - an owner with many runs does not hold up its wavefront */
     const int extra_n = max(n_runs - 1, 0);
     const int incl = wave_inclusive_sum(extra_n);
-    const int extra = 64 + incl - extra_n;
+    const int extra = incl - extra_n;
     n_runq = 64 + __builtin_amdgcn_readlane(incl, 63);
-    if (n_runs > 0 && extra + extra_n > COOP_RUNQ_CAP) {
+    if (extra + extra_n > COOP_RUNQ_CAP - 64) {
       /* queue full: neutralise the part of the reservation that lies inside the queue */
-      for (int j = extra; j < COOP_RUNQ_CAP; j++) W->runq[j] = make_uint2(0xffffffffu, 0u);
+      for (int j = extra; j < COOP_RUNQ_CAP - 64; j++) W->more[j] = 0xffffffffu;
       serial = true;
       n_runs = 0;
     }
+    uint2 e0 = make_uint2(0xffffffffu, 0u);
     if (n_runs > 0) {
-#ifdef DSIM_STATS
-      atomicAdd(&dsim_stats[1], (unsigned long long)((sw.ulx - sw.llx) * (sw.uly - sw.lly) * (sw.ulz - sw.llz)));
-      atomicAdd(&dsim_stats[2], (unsigned long long)n_runs);
-#endif
-      push_runs(ms, sw, fr, W, lane, extra);
-    } else {
-      W->runq[lane] = make_uint2(0xffffffffu, 0u);
+      e0 = make_run(ms, lane, rp, 0);
+      W->plan_a[lane] = make_int4(rp.a0, rp.b0, rp.c0, rp.c1);
+      W->plan_b[lane] = make_int2(rp.zu0, rp.nb | (rp.nc << 8));
+      for (int j = 1; j < n_runs; j++) W->more[extra + j - 1] = (unsigned)lane | ((unsigned)j << 6);
     }
+    W->first[lane] = e0;
     n_runq = min(n_runq, COOP_RUNQ_CAP);
   }
   T_MARK(W, lane, 12);
@@ -411,6 +449,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
    * is nearly full, the items are drained into the survivor pool, the pool is flushed (fp64 tests,
    * per-owner minimum) whenever it holds 64 - so no queue size limits the amount of work per pass */
   {
+    const MeshDev &ms = fresh_params<KA>(p_arg).mesh;
+    const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1; /* = xs[nx], ys[ny], zs[nz] */
     const int lk = ms.lk;
     const unsigned cmask = (1u << (3 * lk)) - 1u;
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
@@ -422,7 +462,18 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       while (cursor < n_runq && n_items <= COOP_ITEM_CAP - 64) {
         const int idx = cursor + lane;
         uint2 e = make_uint2(0xffffffffu, 0u);
-        if (idx < n_runq) e = W->runq[idx];
+        if (idx < 64) {
+          e = W->first[idx];
+        } else if (idx < n_runq) {
+          const unsigned m = W->more[idx - 64];
+          if (m != 0xffffffffu) {
+            const int o = (int)(m & 63u);
+            const int4 pa = W->plan_a[o];
+            const int2 pb = W->plan_b[o];
+            const RunPlan q = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y & 255, pb.y >> 8};
+            e = make_run(ms, o, q, (int)(m >> 6));
+          }
+        }
         int first = 0, cnt = 0;
         if (e.x != 0xffffffffu) {
           STAT_LANE(5);
@@ -517,17 +568,16 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           /* A triangle reaches the pool through every cell it shares with the segment's box (17 % of the survivors on
            * the neuron were repeats): the owner's last survivors are remembered in a 2-way hashed table and a repeat
            * is dropped - the fp64 test of the same triangle and ray returns the same d, and the first copy is already
-           * in the pool or has been tested.  Only for the unshifted image (the table holds the triangle alone); of
-           * two lanes that offer the same triangle at once exactly one sees the other's entry. */
+           * in the pool or has been tested.  Only for the unshifted image (the table holds the triangle alone) and
+           * only for a lane's first survivor (one LDS atomic per lane and trip; a lane rarely has two); of two lanes
+           * that offer the same triangle at once exactly one sees the other's entry. */
           if (alive && !shifted) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              if (!(alive >> u & 1u)) continue;
-              const unsigned t = (unsigned)__float_as_int(q2[u].z);
-              if (atomicExch(&W->filt[owner][(t ^ (t >> 1)) & 1u], t) == t) {
-                alive &= ~(1u << u);
-                STAT_LANE(7);
-              }
+            const unsigned u0 = (unsigned)__builtin_ctz(alive);
+            const float tf = u0 == 0 ? q2[0].z : (u0 == 1 ? q2[1].z : (u0 == 2 ? q2[2].z : q2[3].z));
+            const unsigned t = (unsigned)__float_as_int(tf);
+            if (atomicExch(&W->filt[owner][(t ^ (t >> 1)) & 1u], t) == t) {
+              alive &= alive - 1u;
+              STAT_LANE(7);
             }
           }
 #endif
@@ -561,6 +611,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   }
   /* ---- stage 4: resolve (simulations.py:986-997) */
   if (act) {
+    const WalkParams &p = fresh_params<KA>(p_arg);
+    const MeshDev &ms = p.mesh;
     double d = DS_INF;
     int tri = 0;
     bool redo = serial || W->overflow[lane];
@@ -577,7 +629,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       STAT_LANE(9);
       STAT_WAVE(9);
       BestHit best = {DS_INF, 0};
-      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0, fr); /* recomputed rather than kept in registers through the drain stages */
+      SubvoxelWalk sw; /* recomputed rather than kept in registers through the drain stages */
+      FineRange fr;
+      segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0, fr);
       iteration_serial(ms, sw, r0, step, xs, ys, zs, best);
       d = best.d;
       tri = best.tri;

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void mesh_pass_kernel(const WalkParams p, cons
     bool done = false;
     for (int pass = 0; a.n_pass == 0 || pass < a.n_pass; pass++) {
       if (__ballot(live && !done) == 0ULL) break;
-      const bool fin = coop_iteration(r, step, sl, iter_idx, live && !done, false, p, xs, ys, zs, rng, coop, lane);
+      const bool fin = coop_iteration<0>(r, step, sl, iter_idx, live && !done, false, p, xs, ys, zs, rng, coop, lane);
       if (live && !done && fin) done = true;
     }
     flags = done ? 1 : 0;

@@ -12,9 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
-NAMES = ["reflect-loop iterations", "subvoxels visited", "non-empty subvoxels", "non-empty micro-cells",
-         "record batches (4)", "cell tasks (incl. empty cells)", "AABB pass -> fp64 test", "duplicate survivors (same owner, same list entry)",
-         "coop: cell scanned serially", "coop: survivor overflow redo", "coop: whole iteration serial"]
+NAMES = ["reflect-loop iterations", "subvoxels in range", "runs of fine cells queued", "non-empty runs",
+         "record batches (4)", "run tasks (incl. empty)", "AABB pass -> fp64 test", "repeated survivors dropped (same owner, same triangle)",
+         "serial: subvoxels scanned by the owner", "serial: iterations redone (queues full / tie)", "-"]
 
 
 def main():

@@ -13,10 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
-NAMES = {0: "random step + loop head", 1: "pass set-up (LDS init, sync)", 2: "stage 1a: queries, subvoxel tasks",
-         12: "stage 1b: subvoxel look-up, cell tasks", 13: "stage 1c: cell look-up, items", 3: "sync after stage 1",
+NAMES = {0: "random step + loop head", 1: "pass set-up (LDS init)", 2: "stage 1: subvoxel limits, box, fine cells",
+         12: "stage 1: runs -> queue", 13: "stage 1c: run look-up, items",
          4: "stage 2: item queue, f32 culling", 5: "stage 3A: fp64 tests + atomic min",
-         6: "stage 3B/C: tie-break, publish", 7: "merge pool result / overflow redo", 8: "stage 4: reflection",
+         6: "stage 3B: winner's triangle, ties", 7: "merge pool result / serial redo", 8: "stage 4: reflection",
          9: "position + phase update"}
 
 
