@@ -427,7 +427,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const int incl = wave_inclusive_sum(extra_n);
     const int extra = incl - extra_n;
     n_runq = 64 + __builtin_amdgcn_readlane(incl, 63);
-    if (extra + extra_n > COOP_RUNQ_CAP - 64) {
+    if (extra_n > 0 && extra + extra_n > COOP_RUNQ_CAP - 64) {
       /* queue full: neutralise the part of the reservation that lies inside the queue */
       for (int j = extra; j < COOP_RUNQ_CAP - 64; j++) W->more[j] = 0xffffffffu;
       serial = true;
