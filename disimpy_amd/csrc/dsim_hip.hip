@@ -179,6 +179,8 @@ __global__ void rng_init_kernel(uint64_t seed_s0, uint64_t seed_s1, uint64_t fir
 
 /* ------------------------------------------------------------------ handle --- */
 
+#define DSIM_MAX_GROUPS 4 /* walker groups of a mesh run, each with a stream of its own */
+
 struct dsim_sim {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -209,17 +211,17 @@ struct dsim_sim {
   int resort_steps = 0; /* mesh: 0 = automatic, < 0 = never re-sort the walkers */
   int grad_src = 0;     /* gradient samples from 0 = LDS tiles, 1 = scalar (SMEM) loads */
   int mesh_traversal = 0; /* 0/2 = wavefront-cooperative (clearance map when it pays), 1 = per-lane, 3 = cooperative, never the map, 4 = always */
-  unsigned long long *clear_count = nullptr;
+  unsigned long long *clear_count = nullptr; /* one-off count before the first launch of a call */
   /* per-walker clocks of the cooperative mesh kernel (run_own_clock) */
   int32_t *tcur[2] = {nullptr, nullptr};
-  unsigned long long *progress = nullptr; /* {walkers not yet at t_end, time steps they still have to take, most left} */
+  /* per group two sets of {walkers not yet at t_end, time steps they still have to take, most left, walkers in a clear
+   * cell}: launch k fills set k & 1 while the host still reads the other one; [group][set][4] */
+  unsigned long long *counters = nullptr;
   /* second walker group of a grouped run (run_own_clock): its own stream, sort scratch and counters */
-  hipStream_t grp_stream = nullptr;
-  void *grp_sort_tmp = nullptr;
-  size_t grp_sort_tmp_bytes = 0;
-  unsigned long long *grp_counters = nullptr; /* [4]: progress (3) + clear count */
-  std::vector<hipEvent_t> grp_walk_ev;
-  int grp_walk_ev_used = 0;
+  hipStream_t grp_stream[DSIM_MAX_GROUPS - 1] = {};
+  std::vector<hipEvent_t> grp_walk_ev[DSIM_MAX_GROUPS - 1];
+  int grp_walk_ev_used[DSIM_MAX_GROUPS - 1] = {};
+  int last_groups = 1;
   double last_walk_busy_ms = 0; /* time during which at least one walk kernel was running */
   double last_clear_frac = 0;
   /* spatial re-sorting (mesh): alternates of phase/exc, original-index maps, sort scratch */
@@ -236,11 +238,13 @@ struct dsim_sim {
   bool recording = false;        /* dsim_set_recording: keep the positions of every step of a run */
   int rec_t0 = 0, rec_t1 = 0;    /* time range held in traj after a recorded run */
   uint8_t *exc_alt = nullptr;
-  int32_t *orig[2] = {nullptr, nullptr}, *perm = nullptr, *iota = nullptr;
-  uint32_t *keys[2] = {nullptr, nullptr};
+  int32_t *orig[2] = {nullptr, nullptr};
+  /* counting sort (sort_count / sort_scan / sort_scatter kernels): bin of every walker, and per walker group a
+   * histogram and the bins' cursors */
+  uint32_t *bin_of = nullptr;
+  uint32_t *sort_hist[DSIM_MAX_GROUPS] = {}, *sort_offs[DSIM_MAX_GROUPS] = {};
+  int sort_bits = 0;
   int orig_cur = 0;
-  void *sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
 };
 
 static int ensure_staging(dsim_sim *h, size_t bytes) {
@@ -273,21 +277,21 @@ extern "C" int dsim_destroy(dsim_handle h) {
   if (h->clear_count) (void)hipFree(h->clear_count);
   for (int b = 0; b < 2; b++)
     if (h->tcur[b]) (void)hipFree(h->tcur[b]);
-  if (h->progress) (void)hipFree(h->progress);
-  if (h->grp_sort_tmp) (void)hipFree(h->grp_sort_tmp);
-  if (h->grp_counters) (void)hipFree(h->grp_counters);
-  for (hipEvent_t e : h->grp_walk_ev) (void)hipEventDestroy(e);
-  if (h->grp_stream) (void)hipStreamDestroy(h->grp_stream);
+  if (h->counters) (void)hipFree(h->counters);
+  for (int g = 0; g < DSIM_MAX_GROUPS - 1; g++) {
+    for (hipEvent_t e : h->grp_walk_ev[g]) (void)hipEventDestroy(e);
+    if (h->grp_stream[g]) (void)hipStreamDestroy(h->grp_stream[g]);
+  }
   if (h->phase_alt) (void)hipFree(h->phase_alt);
   if (h->traj) (void)hipFree(h->traj);
   if (h->exc_alt) (void)hipFree(h->exc_alt);
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < 2; b++)
     if (h->orig[b]) (void)hipFree(h->orig[b]);
-    if (h->keys[b]) (void)hipFree(h->keys[b]);
+  for (int g = 0; g < DSIM_MAX_GROUPS; g++) {
+    if (h->sort_hist[g]) (void)hipFree(h->sort_hist[g]);
+    if (h->sort_offs[g]) (void)hipFree(h->sort_offs[g]);
   }
-  if (h->perm) (void)hipFree(h->perm);
-  if (h->iota) (void)hipFree(h->iota);
-  if (h->sort_tmp) (void)hipFree(h->sort_tmp);
+  if (h->bin_of) (void)hipFree(h->bin_of);
   free_mesh(h->mesh);
   for (hipEvent_t e : h->walk_ev) (void)hipEventDestroy(e);
   for (int b = 0; b < 2; b++) {
@@ -604,41 +608,70 @@ static int ensure_sort_buffers(dsim_sim *h) {
   const int64_t n = h->n;
   HIP_TRY(hipMalloc(&h->phase_alt, (size_t)h->M * n * sizeof(double)));
   HIP_TRY(hipMalloc(&h->exc_alt, n));
-  for (int b = 0; b < 2; b++) {
-    HIP_TRY(hipMalloc(&h->orig[b], n * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&h->keys[b], n * sizeof(uint32_t)));
+  for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&h->orig[b], n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&h->bin_of, n * sizeof(uint32_t)));
+  /* 64^3 bins of the periodic voxel; measured on C5b at 1e7 walkers: 32^3 ... 256^3 bins give the same walk-kernel rate
+   * (1.24e10 +- 0.3 %) - what matters is that a wavefront's walkers share a neighbourhood, not their order inside it -
+   * and the single-workgroup scan of 2^24 bins costs 3.5 ms (DSIM_SORT_BITS: tuning runs) */
+  h->sort_bits = 18;
+  if (const char *e = getenv("DSIM_SORT_BITS")) {
+    const int v = atoi(e);
+    if (v >= 6 && v <= 24) h->sort_bits = v;
   }
-  HIP_TRY(hipMalloc(&h->perm, n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&h->iota, n * sizeof(int32_t)));
-  iota_kernel<<<grid_for(n, 256), 256, 0, h->stream>>>(h->iota, n);
-  HIP_TRY(hipGetLastError());
-  size_t bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 31, h->stream));
-  HIP_TRY(hipMalloc(&h->sort_tmp, bytes));
+  const size_t n_bins = ((size_t)1 << h->sort_bits) + 1;
+  for (int g = 0; g < DSIM_MAX_GROUPS; g++) {
+    HIP_TRY(hipMalloc(&h->sort_hist[g], n_bins * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->sort_offs[g], n_bins * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(h->sort_hist[g], 0, n_bins * sizeof(uint32_t), h->stream));
+  }
   for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&h->tcur[b], n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&h->progress, 3 * sizeof(unsigned long long)));
-  h->sort_tmp_bytes = bytes;
+  HIP_TRY(hipMalloc(&h->counters, DSIM_MAX_GROUPS * 2 * 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   h->sort_ready = true;
   return DSIM_OK;
 }
 
-/* sort the walkers of the current state buffer by Morton key; flips h->cur */
-static int resort_walkers(dsim_sim *h, bool first, bool clocks = false, int32_t t_end = 0, bool by_steps_left = false) {
+/* Sort the walkers of the current state buffer into Morton bins (three kernels, see dsim_kernels.h); flips h->cur.
+ * `grp`: which histogram / cursor arrays to use (a walker group of run_own_clock is a view of the handle with its own).
+ * count_clear: also count the walkers in a clear cell of `clear_map` into *count_clear; zero4: four counters the scan
+ * kernel clears on the way (for the launch after this one). */
+static int resort_walkers(dsim_sim *h, bool first, bool clocks = false, int32_t t_end = 0, bool by_steps_left = false, int grp = 0,
+                          const MeshDev *clear_map = nullptr, unsigned long long *count_clear = nullptr, unsigned long long *zero4 = nullptr) {
   const int64_t n = h->n;
   const int g = grid_for(n, 256);
   const int c = h->cur, o = 1 - h->cur;
   const DevMesh &dm = h->mesh;
   /* the clocks travel with the state buffers: tcur[cur] belongs to x[cur] */
-  morton_key_kernel<<<g, 256, 0, h->stream>>>(h->x[c], h->y[c], h->z[c], n, dm.inv_l[0], dm.inv_l[1], dm.inv_l[2], h->keys[0],
-                                              clocks ? h->tcur[c] : nullptr, t_end, by_steps_left ? 1 : 0);
+  SortParams sp = {};
+  sp.x = h->x[c], sp.y = h->y[c], sp.z = h->z[c];
+  sp.n = n;
+  sp.inv_lx = dm.inv_l[0], sp.inv_ly = dm.inv_l[1], sp.inv_lz = dm.inv_l[2];
+  sp.tcur = clocks ? h->tcur[c] : nullptr;
+  sp.t_end = t_end;
+  sp.by_steps_left = by_steps_left ? 1 : 0;
+  sp.bits = h->sort_bits;
+  sp.bin_of = h->bin_of;
+  sp.hist = h->sort_hist[grp];
+  sp.clear_count = clear_map != nullptr ? count_clear : nullptr;
+  const MeshDev no_map = {};
+  sort_count_kernel<<<g, 256, 0, h->stream>>>(sp, clear_map != nullptr ? *clear_map : no_map);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)n, 0, 31, h->stream));
-  gather_state_kernel<<<g, 256, 0, h->stream>>>(h->perm, n, h->x[c], h->y[c], h->z[c], h->s0[c], h->s1[c], h->exc, first ? h->iota : h->orig[h->orig_cur],
-                                                h->x[o], h->y[o], h->z[o], h->s0[o], h->s1[o], h->exc_alt, h->orig[1 - h->orig_cur],
-                                                clocks ? h->tcur[c] : nullptr, h->tcur[o]);
+  sort_scan_kernel<<<1, 256, 0, h->stream>>>(h->sort_hist[grp], h->sort_offs[grp], (1 << h->sort_bits) + 1, zero4);
   HIP_TRY(hipGetLastError());
-  dim3 pg(g, h->M);
-  gather_rows_kernel<<<pg, 256, 0, h->stream>>>(h->perm, n, h->phase_stride, h->phase, h->phase_alt);
+  ScatterParams q = {};
+  q.n = n, q.phase_stride = h->phase_stride, q.M = h->M;
+  q.bin_of = h->bin_of, q.offs = h->sort_offs[grp];
+  q.x = h->x[c], q.y = h->y[c], q.z = h->z[c], q.s0 = h->s0[c], q.s1 = h->s1[c];
+  q.exc = h->exc;
+  q.orig = first ? nullptr : h->orig[h->orig_cur];
+  q.tcur = clocks ? h->tcur[c] : nullptr;
+  q.phase = h->phase;
+  q.xo = h->x[o], q.yo = h->y[o], q.zo = h->z[o], q.s0o = h->s0[o], q.s1o = h->s1[o];
+  q.exco = h->exc_alt;
+  q.origo = h->orig[1 - h->orig_cur];
+  q.tcuro = h->tcur[o];
+  q.phaseo = h->phase_alt;
+  sort_scatter_kernel<<<g, 256, 0, h->stream>>>(q);
   HIP_TRY(hipGetLastError());
   std::swap(h->phase, h->phase_alt);
   std::swap(h->exc, h->exc_alt);
@@ -700,7 +733,9 @@ struct WalkGroup {
   int64_t off = 0;
   std::vector<hipEvent_t> *ev = nullptr;
   int *ev_used = nullptr;
-  unsigned long long *progress = nullptr, *clear_count = nullptr;
+  unsigned long long *counters = nullptr; /* [2][4] on the device: see dsim_sim::counters */
+  int launch_no = 0;                      /* launch k uses counter set k & 1 */
+  double clear_frac = -1;                 /* share of walkers in clear cells as of the last launch's sort (-1: unknown) */
   long long unfinished = 0, steps_left = 0, max_left = 0;
   double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
   int budget = INT_MAX, launches_left = 1 << 20;
@@ -708,10 +743,9 @@ struct WalkGroup {
 };
 
 static int walker_groups(const dsim_sim *h) {
-  int want = 0; /* development override: DSIM_GROUPS=1|2 */
+  int want = 0; /* development override: DSIM_GROUPS=1..4 (see include/dsim.h, environment) */
   if (const char *e = getenv("DSIM_GROUPS")) want = atoi(e);
-  if (want == 1) return 1;
-  if (want == 2) return h->n >= 8192 ? 2 : 1;
+  if (want >= 1 && want <= DSIM_MAX_GROUPS) return h->n >= 4096 * (int64_t)want ? want : 1;
   return h->n >= (1 << 18) ? 2 : 1;
 }
 
@@ -719,76 +753,82 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
                          int32_t t_begin, int32_t t_end) {
   const int n_groups = walker_groups(h);
   if (!h->clear_count) HIP_TRY(hipMalloc(&h->clear_count, sizeof(unsigned long long)));
-  WalkGroup grp[2];
-  const int64_t cut = n_groups == 2 ? ((h->n / 2 + 255) & ~(int64_t)255) : h->n;
+  /* Walker groups are index ranges of the handle's arrays.  Cut out of the caller's order every group is a random
+   * sample of the whole substrate - half the walkers per fine cell, wavefronts that straddle twice as many cells - so
+   * the whole shard is sorted in space ONCE first: a group then is a region of the substrate at the shard's full
+   * density (walkers mix across the cut only by diffusion).  Every later sort is a group's own. */
+  bool presorted = false;
+  if (n_groups > 1) {
+    int rc = resort_walkers(h, true);
+    if (rc) return rc;
+    presorted = true;
+  }
+  WalkGroup grp[DSIM_MAX_GROUPS];
+  h->last_groups = n_groups;
+  const int64_t part = ((h->n + n_groups - 1) / n_groups + 255) & ~(int64_t)255; /* whole workgroups */
   for (int k = 0; k < n_groups; k++) {
     WalkGroup &g = grp[k];
     g.v = *h;
-    g.off = k == 0 ? 0 : cut;
-    g.v.n = k == 0 ? cut : h->n - cut;
-    g.ev = k == 0 ? &h->walk_ev : &h->grp_walk_ev;
-    g.ev_used = k == 0 ? &h->walk_ev_used : &h->grp_walk_ev_used;
-    g.progress = h->progress;
-    g.clear_count = h->clear_count;
-    if (k == 1) {
-      if (!h->grp_stream) HIP_TRY(hipStreamCreateWithFlags(&h->grp_stream, hipStreamNonBlocking));
-      if (!h->grp_counters) HIP_TRY(hipMalloc(&h->grp_counters, 4 * sizeof(unsigned long long)));
-      size_t bytes = 0;
-      HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys[0], h->keys[1], h->iota, h->perm, (int)g.v.n, 0, 31, h->grp_stream));
-      if (bytes > h->grp_sort_tmp_bytes) {
-        if (h->grp_sort_tmp) HIP_TRY(hipFree(h->grp_sort_tmp));
-        h->grp_sort_tmp = nullptr;
-        h->grp_sort_tmp_bytes = 0;
-        HIP_TRY(hipMalloc(&h->grp_sort_tmp, bytes));
-        h->grp_sort_tmp_bytes = bytes;
-      }
-      g.v.stream = h->grp_stream;
-      g.v.sort_tmp = h->grp_sort_tmp;
-      g.v.sort_tmp_bytes = h->grp_sort_tmp_bytes;
-      g.progress = h->grp_counters;
-      g.clear_count = h->grp_counters + 3;
+    g.off = std::min<int64_t>(h->n, k * part);
+    g.v.n = std::min<int64_t>(h->n, (k + 1) * part) - g.off;
+    g.ev = k == 0 ? &h->walk_ev : &h->grp_walk_ev[k - 1];
+    g.ev_used = k == 0 ? &h->walk_ev_used : &h->grp_walk_ev_used[k - 1];
+    g.counters = h->counters + k * 8;
+    if (k >= 1) {
+      if (!h->grp_stream[k - 1]) HIP_TRY(hipStreamCreateWithFlags(&h->grp_stream[k - 1], hipStreamNonBlocking));
+      g.v.stream = h->grp_stream[k - 1];
       for (int b = 0; b < 2; b++) {
         g.v.x[b] += g.off, g.v.y[b] += g.off, g.v.z[b] += g.off, g.v.s0[b] += g.off, g.v.s1[b] += g.off;
-        g.v.tcur[b] += g.off, g.v.orig[b] += g.off, g.v.keys[b] += g.off;
+        g.v.tcur[b] += g.off, g.v.orig[b] += g.off;
       }
-      g.v.phase += g.off, g.v.phase_alt += g.off, g.v.exc += g.off, g.v.exc_alt += g.off, g.v.perm += g.off;
-      /* iota is NOT moved: a group numbers its walkers from 0 */
+      g.v.phase += g.off, g.v.phase_alt += g.off, g.v.exc += g.off, g.v.exc_alt += g.off, g.v.bin_of += g.off;
     }
+    g.permuted = presorted; /* orig[] already holds the walkers' original indices */
     g.unfinished = g.v.n;
     g.steps_left = (long long)g.v.n * (t_end - t_begin);
     g.max_left = t_end - t_begin;
   }
-  h->grp_walk_ev_used = 0;
+  for (int k = 0; k < DSIM_MAX_GROUPS - 1; k++) h->grp_walk_ev_used[k] = 0;
+  HIP_TRY(hipMemsetAsync(h->counters, 0, DSIM_MAX_GROUPS * 2 * 4 * sizeof(unsigned long long), h->stream));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  if (n_groups == 2) HIP_TRY(hipStreamWaitEvent(h->grp_stream, h->ev0, 0)); /* after whatever the handle's stream still holds */
+  for (int k = 1; k < n_groups; k++) HIP_TRY(hipStreamWaitEvent(grp[k].v.stream, h->ev0, 0)); /* after whatever the handle's stream still holds */
   for (int k = 0; k < n_groups; k++) {
     fill_i32_kernel<<<grid_for(grp[k].v.n, 256), 256, 0, grp[k].v.stream>>>(grp[k].v.tcur[grp[k].v.cur], grp[k].v.n, t_begin);
     HIP_TRY(hipGetLastError());
   }
-  /* one launch of a group: re-sort, (clearance map decision,) walk kernel, progress counters */
+  /* One launch of a group = four kernels: the three of the re-sort and the walk kernel, which adds up the progress
+   * counters itself; the counters come back with one small copy.  (Round 2: ~30 dispatches - keys, hipcub's radix
+   * sort, two gathers, two memsets, progress - each of which had to find a wavefront slot between the other group's
+   * workgroups.) */
   auto issue = [&](WalkGroup &g) -> int {
     dsim_sim *v = &g.v;
     if (--g.launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
     /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
      * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
     g.budget = g.max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(g.passes_per_step * resort) + 2;
-    int rc = resort_walkers(v, !g.permuted, true, t_end, g.budget == INT_MAX && g.max_left < t_end - t_begin);
-    if (rc) return rc;
-    g.permuted = true;
     WalkParams q = p;
-    if (clear_auto) {
+    if (clear_auto && g.clear_frac < 0) {
       /* The map pays when whole wavefronts are clear (they then run at the cost of free diffusion); with a
        * minority of clear walkers scattered over the wavefronts its two look-ups per step cost more than the
-       * skipped passes save (neuron, walkers inside: 21 % clear, -1.5 %).  Decide per launch from the share
-       * of walkers that are clear right now - results do not depend on the choice. */
-      HIP_TRY(hipMemsetAsync(g.clear_count, 0, sizeof(unsigned long long), v->stream));
-      clear_count_kernel<<<grid_for(v->n, 256), 256, 0, v->stream>>>(v->x[v->cur], v->y[v->cur], v->z[v->cur], v->n, clear_map, g.clear_count);
+       * skipped passes save (neuron, walkers inside: 21 % clear, -1.5 %).  Decided per launch from the share of
+       * walkers that were clear at the PREVIOUS launch's sort (counted there in passing; the share moves slowly and
+       * results do not depend on the choice) - only the first launch of a call has to count and wait. */
+      HIP_TRY(hipMemsetAsync(h->clear_count, 0, sizeof(unsigned long long), v->stream));
+      clear_count_kernel<<<grid_for(v->n, 256), 256, 0, v->stream>>>(v->x[v->cur], v->y[v->cur], v->z[v->cur], v->n, clear_map, h->clear_count);
       HIP_TRY(hipGetLastError());
       unsigned long long cnt = 0;
-      HIP_TRY(hipMemcpyAsync(&cnt, g.clear_count, sizeof(cnt), hipMemcpyDeviceToHost, v->stream));
+      HIP_TRY(hipMemcpyAsync(&cnt, h->clear_count, sizeof(cnt), hipMemcpyDeviceToHost, v->stream));
       HIP_TRY(hipStreamSynchronize(v->stream));
-      h->last_clear_frac = (double)cnt / (double)v->n;
-      q.mesh.clear_idx = h->last_clear_frac >= 0.4 ? clear_map.clear_idx : nullptr;
+      g.clear_frac = (double)cnt / (double)v->n;
+    }
+    unsigned long long *set = g.counters + 4 * (g.launch_no & 1), *other = g.counters + 4 * ((g.launch_no + 1) & 1);
+    int rc = resort_walkers(v, !g.permuted, true, t_end, g.budget == INT_MAX && g.max_left < t_end - t_begin, (int)(&g - grp),
+                            clear_auto ? &clear_map : nullptr, set + 3, other);
+    if (rc) return rc;
+    g.permuted = true;
+    if (clear_auto) {
+      h->last_clear_frac = g.clear_frac;
+      q.mesh.clear_idx = g.clear_frac >= 0.4 ? clear_map.clear_idx : nullptr;
     }
     const int c = v->cur;
     q.n = v->n; /* q.phase_stride stays the handle's */
@@ -804,6 +844,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     q.traj = nullptr;
     q.tcur = v->tcur[c];
     q.iter_budget = g.budget;
+    q.progress = set;
     q.m0 = 0;
     q.mc = std::min(mb, h->M);
     q.write_state = true;
@@ -821,18 +862,17 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used + 1], v->stream));
     *g.ev_used += 2;
     h->last_launches++;
-    HIP_TRY(hipMemsetAsync(g.progress, 0, 3 * sizeof(unsigned long long), v->stream));
-    progress_kernel<<<grid_for(v->n, 256), 256, 0, v->stream>>>(v->tcur[c], v->n, t_end, g.progress);
-    HIP_TRY(hipGetLastError());
     g.inflight = true;
     return DSIM_OK;
   };
   /* wait for the group's launch and read how far its walkers got */
   auto collect = [&](WalkGroup &g) -> int {
-    unsigned long long pr[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(pr, g.progress, sizeof(pr), hipMemcpyDeviceToHost, g.v.stream));
+    unsigned long long pr[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(pr, g.counters + 4 * (g.launch_no & 1), sizeof(pr), hipMemcpyDeviceToHost, g.v.stream));
     HIP_TRY(hipStreamSynchronize(g.v.stream));
     g.inflight = false;
+    g.launch_no++;
+    if (clear_auto) g.clear_frac = (double)pr[3] / (double)g.v.n;
     const long long done = g.steps_left - (long long)pr[1];
     if (done > 0 && g.budget != INT_MAX) {
       const double measured = (double)g.budget * (double)g.unfinished / (double)done; /* an upper estimate: finished lanes idle */
@@ -866,32 +906,36 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
   };
   const int loop_rc = drive();
   /* whatever happened, the walker order is put back before anything is reported (getters must never see Morton
-   * order), and the halves end up in the same buffers */
+   * order).  Every sort flips a group between the two sets of state buffers; groups that ended in the other set
+   * than group 0 are copied across (their own region of that set is free), then ONE scatter over the whole shard
+   * takes every walker back to its original index - the groups' orig[] hold indices of the whole shard. */
   const std::string keep = g_err;
   int rc = DSIM_OK;
-  for (int k = 0; k < n_groups && !rc; k++)
-    if (grp[k].permuted) rc = restore_walker_order(&grp[k].v);
-  if (!rc) {
-    h->cur = grp[0].v.cur;
-    h->orig_cur = grp[0].v.orig_cur;
-    h->phase = grp[0].v.phase, h->phase_alt = grp[0].v.phase_alt;
-    h->exc = grp[0].v.exc, h->exc_alt = grp[0].v.exc_alt;
-    if (n_groups == 2) {
-      const dsim_sim &v = grp[1].v;
-      const int64_t off = grp[1].off, cnt = v.n;
-      auto move = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
-        return dst == src ? hipSuccess : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, v.stream);
-      };
-      const int hc = h->cur, vc = v.cur;
-      hipError_t e = move(h->x[hc] + off, v.x[vc], cnt * sizeof(double));
-      if (e == hipSuccess) e = move(h->y[hc] + off, v.y[vc], cnt * sizeof(double));
-      if (e == hipSuccess) e = move(h->z[hc] + off, v.z[vc], cnt * sizeof(double));
-      if (e == hipSuccess) e = move(h->s0[hc] + off, v.s0[vc], cnt * sizeof(uint64_t));
-      if (e == hipSuccess) e = move(h->s1[hc] + off, v.s1[vc], cnt * sizeof(uint64_t));
+  for (int k = 0; k < n_groups; k++) (void)hipStreamSynchronize(grp[k].v.stream);
+  if (grp[0].permuted) {
+    const dsim_sim &v0 = grp[0].v;
+    for (int k = 1; k < n_groups && !rc; k++) {
+      const dsim_sim &v = grp[k].v;
+      if (v.cur == v0.cur) continue;
+      const int64_t off = grp[k].off, cnt = v.n;
+      auto move = [&](void *dst, const void *src, size_t bytes) -> hipError_t { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream); };
+      hipError_t e = move(h->x[v0.cur] + off, v.x[v.cur], cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->y[v0.cur] + off, v.y[v.cur], cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->z[v0.cur] + off, v.z[v.cur], cnt * sizeof(double));
+      if (e == hipSuccess) e = move(h->s0[v0.cur] + off, v.s0[v.cur], cnt * sizeof(uint64_t));
+      if (e == hipSuccess) e = move(h->s1[v0.cur] + off, v.s1[v.cur], cnt * sizeof(uint64_t));
       for (int m = 0; m < h->M && e == hipSuccess; m++)
-        e = move(h->phase + (int64_t)m * h->phase_stride + off, v.phase + (int64_t)m * h->phase_stride, cnt * sizeof(double));
-      if (e == hipSuccess) e = move(h->exc + off, v.exc, cnt);
+        e = move(v0.phase + (int64_t)m * h->phase_stride + off, v.phase + (int64_t)m * h->phase_stride, cnt * sizeof(double));
+      if (e == hipSuccess) e = move(v0.exc + off, v.exc, cnt);
+      if (e == hipSuccess) e = move(h->orig[v0.orig_cur] + off, v.orig[v.orig_cur], cnt * sizeof(int32_t));
       if (e != hipSuccess) rc = fail(DSIM_ERR_HIP, "merging the walker groups failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+      h->cur = v0.cur;
+      h->orig_cur = v0.orig_cur;
+      h->phase = v0.phase, h->phase_alt = v0.phase_alt;
+      h->exc = v0.exc, h->exc_alt = v0.exc_alt;
+      rc = restore_walker_order(h);
     }
   }
   for (int k = 0; k < n_groups; k++) (void)hipStreamSynchronize(grp[k].v.stream);
@@ -936,7 +980,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   h->last_walk_ms = 0;
   h->last_walk_busy_ms = 0;
   h->walk_ev_used = 0;
-  h->grp_walk_ev_used = 0;
+  for (int k = 0; k < DSIM_MAX_GROUPS - 1; k++) h->grp_walk_ev_used[k] = 0;
   if (t_begin == t_end) return DSIM_OK;
   const int mb_all = pick_mb(h->M, h->meas_per_pass);
   const int passes_all = (h->M + mb_all - 1) / mb_all;
@@ -1448,14 +1492,18 @@ extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) 
 extern "C" int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_walk_ms;
-  if (n_launches) *n_launches = (h->walk_ev_used + h->grp_walk_ev_used) / 2;
+  if (n_launches) {
+    int used = h->walk_ev_used;
+    for (int k = 0; k < DSIM_MAX_GROUPS - 1; k++) used += h->grp_walk_ev_used[k];
+    *n_launches = used / 2;
+  }
   return DSIM_OK;
 }
 
 extern "C" int dsim_last_walk_busy_ms(dsim_handle h, double *ms, int32_t *n_streams) {
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_walk_busy_ms;
-  if (n_streams) *n_streams = h->grp_walk_ev_used > 0 ? 2 : 1;
+  if (n_streams) *n_streams = h->grp_walk_ev_used[0] > 0 ? h->last_groups : 1;
   return DSIM_OK;
 }
 

@@ -121,6 +121,9 @@ struct WalkParams {
    * finish it) or all its walkers have reached t_end.  nullptr: every walker runs [t_begin, t_end). */
   int32_t *tcur;
   int iter_budget;
+  /* with tcur: {walkers not yet at t_end, time steps they still have to take, the most any of them has left}, added up
+   * by the kernel itself at the end of the launch (one atomic each per wavefront); nullptr: not asked */
+  unsigned long long *progress;
 };
 
 /* ---- one walker, one time step, by substrate -------------------------------- */
@@ -622,7 +625,27 @@ DSD void walk_body(const WalkParams &p_arg) {
         }
         T_MARK(coop, lane, 9);
       }
-      if (fresh_params<KA>(p_arg).tcur != nullptr && live) fresh_params<KA>(p_arg).tcur[i] = t0 + k_lane;
+      {
+        const WalkParams &q = fresh_params<KA>(p_arg);
+        if (q.tcur != nullptr) {
+          if (live) q.tcur[i] = t0 + k_lane;
+          if (q.progress != nullptr) {
+            int left = live ? max(0, q.t_end - (t0 + k_lane)) : 0;
+            const unsigned long long unfinished = __ballot(left > 0);
+            int sum = left, mx = left;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+              sum += __shfl_down(sum, off, 64);
+              mx = max(mx, __shfl_down(mx, off, 64));
+            }
+            if (lane == 0 && unfinished) {
+              atomicAdd(&q.progress[0], (unsigned long long)__popcll(unfinished));
+              atomicAdd(&q.progress[1], (unsigned long long)sum);
+              atomicMax(&q.progress[2], (unsigned long long)mx);
+            }
+          }
+        }
+      }
 #ifdef DSIM_TIMERS
       if (lane == 0)
         for (int q = 0; q < 16; q++) atomicAdd(&dsim_timers[q], coop->tacc[q]);
@@ -889,80 +912,167 @@ DSD uint32_t spread10(uint32_t v) { /* 10 bits -> every third bit */
   return v;
 }
 
-/* 30-bit Morton code of the position wrapped into the periodic voxel (1024^3 cells).
- * Only a sort key: approximate arithmetic is fine, results never depend on it. */
-__global__ void morton_key_kernel(const double *x, const double *y, const double *z, int64_t n, double inv_lx, double inv_ly,
-                                  double inv_lz, uint32_t *keys, const int32_t *tcur, int32_t t_end, int by_steps_left) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (tcur != nullptr && tcur[i] >= t_end) { /* per-walker clocks: walkers that are done go to the end of the order */
-    keys[i] = 0x40000000u;
-    return;
-  }
-  /* last launch of a call (every walker runs to t_end): walkers with a similar number of steps left share wavefronts,
-   * so that no lane idles long for its neighbours; within such a class the order is spatial as usual */
-  const uint32_t cls = by_steps_left && tcur != nullptr ? (uint32_t)min(63, (t_end - tcur[i]) >> 5) : 0u;
-  double fx = x[i] * inv_lx, fy = y[i] * inv_ly, fz = z[i] * inv_lz;
+/* ---- the re-sort: a counting sort on the top bits of the Morton code, hand-written (round 2 called hipcub's radix
+ * sort: 21 dispatches of its own per re-sort, each of which had to find a free wavefront slot between the other walker
+ * group's workgroups).  Three kernels per re-sort:
+ *   sort_count_kernel    bin of every walker (kept in bin_of[]), histogram with ONE atomic per wavefront and distinct
+ *                        bin (the walkers arrive nearly sorted: a wavefront holds one to three bins), and - in the same
+ *                        pass over the positions - how many walkers sit in a clear cell of the clearance map;
+ *   sort_scan_kernel     exclusive prefix sum over the bins, one workgroup (the histogram is zeroed for the next
+ *                        time, as are the counters the NEXT launch will use);
+ *   sort_scatter_kernel  every walker takes a slot of its bin (one atomic per wavefront and bin again) and moves there
+ *                        with everything it owns: position, RNG state, iter_exc, clock, original index, phases.
+ * The order inside a bin is whatever the atomics make it - walkers do not interact, results cannot depend on it, and
+ * the order is undone before anything leaves the run.  Bins are 2^bits cells of the periodic voxel in Morton order
+ * (bits = 18: 64^3 cells of about 3.4 um on the neuron - a walker moves 2.7 um in the 256 steps between two re-sorts),
+ * plus one last bin for walkers that have reached the end of the call. */
+DSD uint32_t walker_morton30(double x, double y, double z, double inv_lx, double inv_ly, double inv_lz) {
+  double fx = x * inv_lx, fy = y * inv_ly, fz = z * inv_lz;
   fx -= __builtin_floor(fx);
   fy -= __builtin_floor(fy);
   fz -= __builtin_floor(fz);
+  /* only a sort key: approximate arithmetic is fine, results never depend on it */
   uint32_t ix = fx == fx ? (uint32_t)min(1023, max(0, (int)(fx * 1024.0))) : 0u;
   uint32_t iy = fy == fy ? (uint32_t)min(1023, max(0, (int)(fy * 1024.0))) : 0u;
   uint32_t iz = fz == fz ? (uint32_t)min(1023, max(0, (int)(fz * 1024.0))) : 0u;
-  const uint32_t morton = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
-  keys[i] = by_steps_left ? (cls << 24) | (morton >> 6) : morton;
+  return (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
 }
 
-/* per-walker clocks: {walkers that have not reached t_end, time steps they still have to take, the most any of them has left} */
-__global__ void progress_kernel(const int32_t *tcur, int64_t n, int32_t t_end, unsigned long long *out3) {
+struct SortParams {
+  const double *x, *y, *z;
+  int64_t n;
+  double inv_lx, inv_ly, inv_lz;
+  const int32_t *tcur; /* per-walker clocks: walkers at t_end go to the last bin (nullptr: no clocks) */
+  int32_t t_end;
+  int by_steps_left;   /* last launch of a call: 64 classes of steps left first, space inside a class */
+  int bits;            /* bins = (1 << bits) + 1 */
+  uint32_t *bin_of;    /* [n] */
+  uint32_t *hist;      /* [(1 << bits) + 1], zero on entry */
+  unsigned long long *clear_count; /* += walkers in a clear cell (nullptr: not asked) */
+};
+
+/* one atomic per distinct value of `bin` among the valid lanes of the wavefront; returns what the atomic returned plus
+ * the lane's rank among the lanes with the same bin (the lane's own slot when `counter` is a cursor) */
+DSD uint32_t wave_bin_add(uint32_t *counter, uint32_t bin, bool valid) {
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t slot = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = (int)__ffsll((long long)todo) - 1;
+    const uint32_t b = (uint32_t)__shfl((int)bin, leader, 64);
+    const unsigned long long same = __ballot(valid && bin == b) & todo;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&counter[b], (uint32_t)__popcll(same));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (valid && bin == b) slot = base + (uint32_t)__popcll(same & ((1ULL << lane) - 1ULL));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+__global__ __launch_bounds__(256) void sort_count_kernel(const SortParams p, const MeshDev clear_map) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int left = 0;
-  if (i < n) left = max(0, t_end - tcur[i]);
-  const unsigned long long m = __ballot(left > 0);
-  int sum = left, mx = left;
+  const bool valid = i < p.n;
+  uint32_t bin = 0;
+  bool clear = false;
+  if (valid) {
+    const double x = p.x[i], y = p.y[i], z = p.z[i];
+    if (p.tcur != nullptr && p.tcur[i] >= p.t_end) {
+      bin = 1u << p.bits;
+    } else {
+      const uint32_t m = walker_morton30(x, y, z, p.inv_lx, p.inv_ly, p.inv_lz);
+      if (p.by_steps_left && p.tcur != nullptr) {
+        /* walkers with a similar number of steps left share wavefronts, so that no lane idles long for its neighbours */
+        const uint32_t cls = (uint32_t)min(63, (p.t_end - p.tcur[i]) >> 5);
+        bin = (cls << (p.bits - 6)) | (m >> (36 - p.bits));
+      } else {
+        bin = m >> (30 - p.bits);
+      }
+    }
+    p.bin_of[i] = bin;
+    if (p.clear_count != nullptr) {
+      const V3 r = {x, y, z};
+      clear = walker_is_clear(clear_map, r);
+    }
+  }
+  (void)wave_bin_add(p.hist, bin, valid);
+  if (p.clear_count != nullptr) {
+    const unsigned long long m = __ballot(clear);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(p.clear_count, (unsigned long long)__popcll(m));
+  }
+}
+
+/* exclusive prefix sum of hist[0 .. n_bins) into offs, hist zeroed; one workgroup of 256 threads walks the bins in
+ * tiles of 1024 (coalesced 16-byte loads).  zero4: four counters to clear for the launch after this one. */
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *hist, uint32_t *offs, int n_bins, unsigned long long *zero4) {
+  __shared__ uint32_t wsum[4];
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (zero4 != nullptr && t < 4) zero4[t] = 0ULL;
+  uint32_t carry = 0;
+  for (int base = 0; base < n_bins; base += 1024) {
+    const int b0 = base + 4 * t;
+    uint32_t v[4];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sum += __shfl_down(sum, off, 64);
-    mx = max(mx, __shfl_down(mx, off, 64));
+    for (int q = 0; q < 4; q++) {
+      v[q] = b0 + q < n_bins ? hist[b0 + q] : 0u;
+      if (b0 + q < n_bins) hist[b0 + q] = 0u;
+    }
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = (uint32_t)wave_inclusive_sum((int)mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (b0 + q < n_bins) offs[b0 + q] = run;
+      run += v[q];
+    }
+    carry += total;
+    __syncthreads();
   }
-  if ((threadIdx.x & 63) == 0 && m) {
-    atomicAdd(&out3[0], (unsigned long long)__popcll(m));
-    atomicAdd(&out3[1], (unsigned long long)sum);
-    atomicMax(&out3[2], (unsigned long long)mx);
-  }
+}
+
+struct ScatterParams {
+  int64_t n, phase_stride;
+  int M;
+  const uint32_t *bin_of;
+  uint32_t *offs; /* cursors: first free slot of every bin */
+  const double *x, *y, *z;
+  const uint64_t *s0, *s1;
+  const uint8_t *exc;
+  const int32_t *orig; /* nullptr: the walkers are in their original order (orig = index) */
+  const int32_t *tcur; /* nullptr: no clocks */
+  const double *phase;
+  double *xo, *yo, *zo;
+  uint64_t *s0o, *s1o;
+  uint8_t *exco;
+  int32_t *origo, *tcuro;
+  double *phaseo;
+};
+
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const ScatterParams p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < p.n;
+  const uint32_t bin = valid ? p.bin_of[i] : 0u;
+  const uint32_t j = wave_bin_add(p.offs, bin, valid);
+  if (!valid) return;
+  p.xo[j] = p.x[i];
+  p.yo[j] = p.y[i];
+  p.zo[j] = p.z[i];
+  p.s0o[j] = p.s0[i];
+  p.s1o[j] = p.s1[i];
+  p.exco[j] = p.exc[i];
+  p.origo[j] = p.orig != nullptr ? p.orig[i] : (int32_t)i;
+  if (p.tcur != nullptr) p.tcuro[j] = p.tcur[i];
+  for (int m = 0; m < p.M; m++) p.phaseo[(int64_t)m * p.phase_stride + j] = p.phase[(int64_t)m * p.phase_stride + i];
 }
 
 __global__ void fill_i32_kernel(int32_t *v, int64_t n, int32_t value) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = value;
-}
-
-__global__ void iota_kernel(int32_t *v, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = (int32_t)i;
-}
-
-/* slot i of the new order takes the walker that sat in slot perm[i] */
-__global__ void gather_state_kernel(const int32_t *perm, int64_t n, const double *x, const double *y, const double *z,
-                                    const uint64_t *s0, const uint64_t *s1, const uint8_t *exc, const int32_t *orig,
-                                    double *xo, double *yo, double *zo, uint64_t *s0o, uint64_t *s1o, uint8_t *exco,
-                                    int32_t *origo, const int32_t *tcur, int32_t *tcuro) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int32_t j = perm[i];
-  if (tcur != nullptr) tcuro[i] = tcur[j];
-  xo[i] = x[j];
-  yo[i] = y[j];
-  zo[i] = z[j];
-  s0o[i] = s0[j];
-  s1o[i] = s1[j];
-  exco[i] = exc[j];
-  origo[i] = orig[j];
-}
-
-__global__ void gather_rows_kernel(const int32_t *perm, int64_t n, int64_t stride, const double *src, double *dst) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[(int64_t)blockIdx.y * stride + i] = src[(int64_t)blockIdx.y * stride + perm[i]];
 }
 
 /* slot i returns to walker index orig[i] */
