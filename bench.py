@@ -301,7 +301,7 @@ def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
     return time.perf_counter() - t0, walk_ms, run_ms, launches, sig
 
 
-def setup_sim(args, w, n_total, a, b, device):
+def setup_sim(args, w, n_total, a, b, device, dist=None):
     """Untimed set-up: everything resident in HBM.  Returns (sim, positions of [a, b), setup_s)."""
     from disimpy_amd import _lib, simulations
 
@@ -314,7 +314,7 @@ def setup_sim(args, w, n_total, a, b, device):
     if cache and os.path.exists(cache) and sub.type == "mesh":
         positions, frames = np.load(cache)[a:b], None
     else:
-        positions, frames = simulations._initial_positions(n_total, sub, 123, True, device, (a, b))
+        positions, frames = simulations._initial_positions(n_total, sub, 123, True, device, (a, b), dist=dist)
         if cache and sub.type == "mesh" and (a, b) == (0, n_total):
             np.save(cache, positions)
     w["frames"] = frames
@@ -357,18 +357,32 @@ def profile_entry(workload):
         return None
 
 
+def lib_sha256():
+    """sha256 of the libdsim_hip.so this process runs (the counters in profiles/ name the build they were taken on)"""
+    import hashlib
+
+    from disimpy_amd import _lib
+
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def secondary_rates(args, device):
     """The other BASELINE configs at a glance (rank 0 of a single-GPU run, after the timed region):
-    C2 and C3 at their full sizes, C4 with 1e6 of its 1e7 walkers."""
+    C2 and C3 at their full sizes; C4 at the per-GPU shares of its 4- and 2-GPU configurations (2.5e6 and 5e6 of
+    1e7 walkers); the headline workload at the per-GPU share of the 8-GPU configuration (1.25e6 walkers)."""
     out = {}
-    for name, n, meas in (("c2", 1_000_000, 1), ("c3", 1_000_000, 1), ("c4", 1_000_000, 1)):
+    for key, name, n, meas in (("c2", "c2", 1_000_000, 1), ("c3", "c3", 1_000_000, 1), ("c4_share_of_4_gpus", "c4", 2_500_000, 1),
+                               ("c4_share_of_2_gpus", "c4", 5_000_000, 1), ("c5b_share_of_8_gpus", "c5b", 1_250_000, 1)):
         w = make_workload(name, n, meas)
         sub, T = w["substrate"], w["gradient"].shape[1]
         sim, _, _ = setup_sim(args, w, n, 0, n, device)
         run_steps(sim, sub, w["frames"], T, 1, None, device, lambda: None)
         el, walk_ms, _, _, sig = run_steps(sim, sub, w["frames"], T, 2, None, device, lambda: None)
         sim.close()
-        out[name] = {"workload": w["label"], "value": n * T * 2 / el, "unit": "spin-steps/s",
+        out[key] = {"workload": w["label"], "value": n * T * 2 / el, "unit": "spin-steps/s",
                      "walk_kernel_spin_steps_per_s": n * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)}
     return out
 
@@ -388,8 +402,12 @@ def launch_ranks(n_ranks, argv, script=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    failed = None
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # rank 0's JSON line is collected while ALL children are watched: a rank that dies first must not leave
+    failed = None   # rank 0 blocked in a collective with nobody looking
     deadline = time.time() + 3600
     pending = set(range(len(procs)))
     while pending and time.time() < deadline:
@@ -407,9 +425,11 @@ def launch_ranks(n_ranks, argv, script=None):
             procs[r].kill()
         for pr in procs:
             pr.wait()
-        sys.stdout.write(out0)
+        reader.join(5)
+        sys.stdout.write(b"".join(chunks).decode())
         raise SystemExit("rank %s failed (exit code %s)" % (failed or ("?", "timeout")))
-    sys.stdout.write(out0)
+    reader.join()
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     return 0
 
@@ -479,7 +499,7 @@ def main(argv=None):
     a, b = sharding.shard_range(n_total, rank, world)
     n_local = b - a
 
-    sim, positions, setup = setup_sim(args, w, n_total, a, b, device)
+    sim, positions, setup = setup_sim(args, w, n_total, a, b, device, dist)
     setup["workload_and_mesh_index_host"] = t_wl
     setup["total"] = sum(setup.values())
     frames = w["frames"]
@@ -516,34 +536,49 @@ def main(argv=None):
     steps_per_launch = T * passes / n_launch
     alg_bytes_per_launch = (80.0 + 16.0 * meas_per_launch) * n_local * steps_per_launch
     alg_gbs = alg_bytes_per_launch * n_launch / (walk_ms_step * 1e-3) / 1e9
+    # ---- counters of the same kernel, collected separately (tools/pmc_profile.py -> profiles/kernel_counters.json).
+    # They are only quoted when they were taken on THIS build of the library (sha256) with this run's kernel
+    # selection; stale or foreign counters yield nulls, never a number.
     prof = profile_entry(args.workload) or {}
-    valu_ws = prof.get("valu_per_wave_step")
-    traffic = prof.get("hbm_bytes_per_walker_launch")  # measured HBM bytes per walker and launch (state in + out + misses)
+    lib_hash = lib_sha256()
+    default_tuning = not (args.block_size or args.tile_steps or args.meas_per_pass or args.gradient_source or args.mesh_traversal
+                          or args.resort_steps or os.environ.get("DSIM_GROUPS") or os.environ.get("DSIM_MICRO")
+                          or os.environ.get("DSIM_SORT_BITS"))
+    counters_match_lib = bool(prof) and prof.get("lib_sha256") == lib_hash
+    counters_match_config = bool(prof) and prof.get("measurements", 1) == M and default_tuning
+    use = prof if (counters_match_lib and counters_match_config) else {}
+    valu_ws = use.get("valu_per_wave_step")
+    traffic = use.get("hbm_bytes_per_walker_launch")  # measured HBM bytes per walker and launch (state in + out + misses)
     traffic = traffic * n_local / streams if traffic else None
     hbm_gbs = (traffic * n_launch / (walk_ms_step * 1e-3) / 1e9) if traffic else None
-    achieved = valu_ws * wave_steps_per_s if valu_ws else None
+    valu_rate = valu_ws * wave_steps_per_s if valu_ws else None
     roofline = {
-        "bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instr/s",
-        "frac": (achieved / VALU_PEAK) if achieved else None,
-        "formula": "VALU wave-instructions per wavefront-step (rocprofv3 SQ_INSTS_VALU / wavefront-steps, "
-                   "profiles/) x wavefront-steps/s (HIP events around every launch of the walk kernel in this run; "
-                   "time with at least one launch running when the shard's two halves overlap on two streams) / "
-                   "(1024 SIMDs x 2.4e9 Hz / 4 cycles per wave64 instruction)",
-        "kernel": kernel_name(sub, M, args), "valu_per_wave_step": valu_ws, "salu_per_wave_step": prof.get("salu_per_wave_step"),
-        "valu_busy_measured": prof.get("valu_busy"), "counters_source": prof.get("source"),
-        "wave_steps_per_s": wave_steps_per_s, "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
-        "streams": streams, "walk_busy_ms_per_step": walk_ms_step, "walk_sum_ms_per_step": walk_sum_step,
+        # the contract's roofline: SURVEY 8d's algorithmic bytes of the launches of this run / the time those launches
+        # took (HIP events on the library's streams), against the HBM peak
+        "bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
         "traffic": traffic,
-        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per walker x "
-                        "this shard's walkers; profiles/)",
-        "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None},
-        "algorithmic_hbm": {
-            "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
-            "bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch, "bytes_per_launch": alg_bytes_per_launch,
-            "caveat": "SURVEY 8d bytes of the reference's step-synchronous formulation; the time-fused kernel keeps "
-                      "walker state in registers and does not move them, so this is not a utilisation (may exceed 1)"},
-        "note": "register-resident fused kernel: bound by vector-ALU issue and dependent index look-ups, not by "
+        "traffic_unit": "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per walker x "
+                        "this shard's walkers; null when the committed counters are not of this library build)",
+        "bytes_per_spin_step": 80.0 + 16.0 * meas_per_launch, "bytes_per_launch": alg_bytes_per_launch,
+        "kernel": kernel_name(sub, M, args), "launches_per_step": n_launch, "avg_launch_ms": avg_launch_ms,
+        "streams": streams, "walk_busy_ms_per_step": walk_ms_step, "walk_sum_ms_per_step": walk_sum_step,
+        "wave_steps_per_s": wave_steps_per_s,
+        "caveat": "the algorithmic bytes are what the reference's step-synchronous kernels must move per spin-step (80 + 16 M); "
+                  "the time-fused kernel keeps walker state in registers, so `frac` compares throughputs, it is not an "
+                  "HBM utilisation - `measured_hbm` is (and shows no wasted traffic)",
+        "measured_hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None},
+        "counters_match_lib": counters_match_lib, "counters_match_config": counters_match_config, "lib_sha256": lib_hash,
+        "counters_source": prof.get("source"),
+        # what actually bounds the kernel: vector-ALU time.  valu_busy_measured = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x
+        # kernel cycles) from the counter run; issue_frac prices every instruction at 4 cycles (the fp64 rate; f32 / integer
+        # instructions of several waves issue in 2), so it overstates - the measured figure is the one to quote
+        "valu": {"valu_busy_measured": use.get("valu_busy"), "valu_per_wave_step": valu_ws,
+                 "salu_per_wave_step": use.get("salu_per_wave_step"), "lds_per_wave_step": use.get("lds_per_wave_step"),
+                 "wait_any_frac": use.get("wait_any_frac"),
+                 "issue_rate": valu_rate, "issue_peak": VALU_PEAK, "issue_frac": (valu_rate / VALU_PEAK) if valu_rate else None,
+                 "issue_unit": "wave-instr/s at 4 cycles per wave64 instruction"},
+        "note": "register-resident fused kernel: bound by vector-ALU time and dependent index look-ups, not by "
                 "HBM.  Deviations from the north star's sketch, measured and kept: the mesh kernel reads triangle "
                 "records through L1/L2 (7 MB index, Morton-sorted walkers) instead of staging lists in LDS, and "
                 "with M <= 2 it reads the gradient samples from global memory (32 B per step out of L1) instead "

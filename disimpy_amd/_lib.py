@@ -19,7 +19,7 @@ SYMBOLS = (
     "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
-    "dsim_write_traj", "dsim_write_traj_line",
+    "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -36,16 +36,6 @@ class DsimError(RuntimeError):
     """A call into libdsim_hip.so failed."""
 
 
-class _MissingSymbol:
-    """Stand-in for an entry point a development build (DSIM_LIB=...) does not export."""
-
-    def __init__(self, name):
-        self.name, self.argtypes, self.restype = name, None, None
-
-    def __call__(self, *a):
-        raise DsimError("%s is not exported by %s" % (self.name, LIB_PATH))
-
-
 def load():
     """Load libdsim_hip.so (built by ``__graft_entry__.build()`` / ``make -C disimpy_amd/csrc``)."""
     global _lib
@@ -58,13 +48,8 @@ def load():
         )
     lib = C.CDLL(LIB_PATH)
     missing = [name for name in SYMBOLS if not hasattr(lib, name)]
-    if missing:
-        if not os.environ.get("DSIM_LIB"):
-            raise DsimError("%s lacks %s: rebuild it (make -C disimpy_amd/csrc)" % (LIB_PATH, ", ".join(missing)))
-        # DSIM_LIB names a development build (older kernels kept for A/B timing): calling a missing entry
-        # point still fails, loudly, at the call
-        for name in missing:
-            setattr(lib, name, _MissingSymbol(name))
+    if missing:  # also for a build named by DSIM_LIB (A/B timing runs): a library that lacks a declared symbol is not loaded
+        raise DsimError("%s lacks %s: rebuild it (make -C disimpy_amd/csrc)" % (LIB_PATH, ", ".join(missing)))
     lib.dsim_last_error.restype = C.c_char_p
     lib.dsim_rng_init.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
     lib.dsim_rng_init_device.argtypes = [_h, C.c_uint64]
@@ -84,9 +69,14 @@ def load():
     lib.dsim_get_positions.argtypes = [_h, _f64p]
     lib.dsim_get_phases.argtypes = [_h, _f64p]
     lib.dsim_get_iter_exc.argtypes = [_h, _u8p]
+    lib.dsim_get_all_signals.argtypes = [_h, _f64p]
     lib.dsim_get_rng_states.argtypes = [_h, _u64p]
     lib.dsim_fill_mesh.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_uint64, _f64p, C.c_int64, _i64p, C.c_int64,
                                    _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, _f64p]
+    lib.dsim_fill_open.argtypes = [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_uint64, _f64p, C.c_int64, _i64p,
+                                   C.c_int64, _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64]
+    lib.dsim_fill_run.argtypes = [_h, C.c_int64, _i64p, _f64p, C.c_int64, _i64p]
+    lib.dsim_fill_close.argtypes = [_h]
     lib.dsim_mesh_subdivide.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p,
                                         _i64p]
     lib.dsim_mesh_clearance_map.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, C.c_double,
@@ -317,6 +307,12 @@ class Sim:
         check(self._lib.dsim_get_phases(self._h, p_f64(out)))
         return out
 
+    def all_signals(self):
+        """(M, n) cos(phase), NaN for walkers with iter_exc set - evaluated on the device (simulations.py:1414-1417)"""
+        out = np.empty((self.M, self.n))
+        check(self._lib.dsim_get_all_signals(self._h, p_f64(out)))
+        return out
+
     def iter_exc(self):
         out = np.zeros(self.n, dtype=np.uint8)
         check(self._lib.dsim_get_iter_exc(self._h, out.ctypes.data_as(_u8p)))
@@ -350,3 +346,50 @@ def fill_mesh(n_points, intra, seed, vertices, faces, voxel_size, xs, ys, zs, n_
                              p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri), len(tri),
                              p_f64(out)))
     return out
+
+
+class FillSession:
+    """The _fill_mesh loop (disimpy/simulations.py:505-579) for the threads [thread_begin, thread_end) of its launches
+    (dsim_fill_open / dsim_fill_run / dsim_fill_close); see disimpy_amd.sharding.fill_mesh_sharded."""
+
+    def __init__(self, thread_begin, thread_end, intra, seed, vertices, faces, voxel_size, xs, ys, zs, n_sv, subvoxel_indices,
+                 triangle_indices, device=0):
+        lib = load()
+        if lib.dsim_device_count() <= 0:
+            raise DsimError("no HIP device visible (need an AMD GPU with ROCm); there is no CPU fallback")
+        v, f = _c(vertices, np.float64), _c(faces, np.int64)
+        vs = _c(voxel_size, np.float64)
+        xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+        nsv = _c(n_sv, np.int64)
+        svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
+        self._lib, self._h = lib, _h()
+        self.n_threads = thread_end - thread_begin
+        check(lib.dsim_fill_open(C.byref(self._h), device, thread_begin, thread_end, int(bool(intra)), seed, p_f64(v), len(v),
+                                 p_i64(f), len(f), p_f64(vs), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri),
+                                 len(tri)))
+
+    def run(self, n_launches, capacity):
+        """-> (counts (n_launches,), points (rows, 3)): accepted candidates per launch and, in (launch, thread) order, the
+        first ``capacity`` of them"""
+        counts = np.zeros(n_launches, dtype=np.int64)
+        pts = np.empty((max(capacity, 1), 3))
+        rows = C.c_int64(0)
+        check(self._lib.dsim_fill_run(self._h, n_launches, p_i64(counts), p_f64(pts), capacity, C.byref(rows)))
+        return counts, pts[: rows.value]
+
+    def close(self):
+        if self._h:
+            self._lib.dsim_fill_close(self._h)
+            self._h = _h()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -473,6 +473,63 @@ extern "C" int dsim_get_phases(dsim_handle h, double *phases) {
   return DSIM_OK;
 }
 
+/* all_signals: cos(phase) with the NaN mask, computed on the device block by block; block k is written by the compute
+ * stream into one of two device buffers, crosses PCIe on the copy stream into one of two pinned buffers, and is copied
+ * out by the host while block k + 1 is already on its way. */
+extern "C" int dsim_get_all_signals(dsim_handle h, double *signals) {
+  if (!h || !signals) return fail(DSIM_ERR_INVALID, "dsim_get_all_signals: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t total = (int64_t)h->M * h->n;
+  const int64_t per = std::min<int64_t>(total, (int64_t)4 << 20); /* 32 MB blocks */
+  const size_t need = (size_t)per * sizeof(double);
+  if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++)
+    if (!h->pin_ev[b]) HIP_TRY(hipEventCreateWithFlags(&h->pin_ev[b], hipEventDisableTiming));
+  if (h->pin_bytes < need) {
+    for (int b = 0; b < 2; b++) {
+      if (h->pin[b]) (void)hipHostFree(h->pin[b]);
+      h->pin[b] = nullptr;
+    }
+    h->pin_bytes = 0;
+    for (int b = 0; b < 2; b++) HIP_TRY(hipHostMalloc(&h->pin[b], need, hipHostMallocDefault));
+    h->pin_bytes = need;
+  }
+  int rc = ensure_staging(h, 2 * need);
+  if (rc) return rc;
+  hipEvent_t done[2] = {nullptr, nullptr};
+  for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+  auto finish = [&](int code) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->copy_stream);
+    for (int b = 0; b < 2; b++) (void)hipEventDestroy(done[b]);
+    return code;
+  };
+  int64_t prev_first = 0, prev_count = 0;
+  int k = 0;
+  for (int64_t first = 0; first < total; first += per, k++) {
+    const int b = k & 1;
+    const int64_t count = std::min(per, total - first);
+    double *dev = (double *)h->staging + (size_t)b * per;
+    all_signals_kernel<<<grid_for(count, 256), 256, 0, h->stream>>>(h->phase, h->exc, h->n, first, count, dev);
+    if (hipGetLastError() != hipSuccess) return finish(fail(DSIM_ERR_HIP, "all_signals_kernel launch failed"));
+    if (hipEventRecord(done[b], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[b], 0) != hipSuccess ||
+        hipMemcpyAsync(h->pin[b], dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess ||
+        hipEventRecord(h->pin_ev[b], h->copy_stream) != hipSuccess)
+      return finish(fail(DSIM_ERR_HIP, "dsim_get_all_signals: copy failed"));
+    if (prev_count) { /* the previous block is consumed before its buffers are reused two blocks later */
+      if (hipEventSynchronize(h->pin_ev[1 - b]) != hipSuccess) return finish(fail(DSIM_ERR_HIP, "dsim_get_all_signals: copy failed"));
+      memcpy(signals + prev_first, h->pin[1 - b], (size_t)prev_count * sizeof(double));
+    }
+    prev_first = first, prev_count = count;
+  }
+  if (prev_count) {
+    const int b = (k - 1) & 1;
+    if (hipEventSynchronize(h->pin_ev[b]) != hipSuccess) return finish(fail(DSIM_ERR_HIP, "dsim_get_all_signals: copy failed"));
+    memcpy(signals + prev_first, h->pin[b], (size_t)prev_count * sizeof(double));
+  }
+  return finish(DSIM_OK);
+}
+
 extern "C" int dsim_get_iter_exc(dsim_handle h, uint8_t *exc) {
   if (!h || !exc) return fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument");
   HIP_TRY(hipSetDevice(h->device));
@@ -1576,84 +1633,96 @@ extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, do
 /* accepted point i of this launch goes to row have + prefix[i] (rows beyond n are dropped); the last thread leaves
  * the new count in the other slot of `have` (two slots, alternating, so that nobody reads what it writes) */
 __global__ void fill_scatter_kernel(const double *px, const double *py, const double *pz, const int32_t *flag, const int32_t *pref,
-                                    int64_t n, const int64_t *have_in, int64_t *have_out, double *out) {
+                                    int64_t n, int64_t capacity, const int64_t *have_in, int64_t *have_out, int64_t *count_out, double *out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t base = *have_in;
-  if (i == n - 1) *have_out = base + pref[i] + flag[i];
+  if (i == n - 1) {
+    *have_out = base + pref[i] + flag[i];
+    *count_out = (int64_t)pref[i] + flag[i];
+  }
   if (!flag[i]) return;
   int64_t row = base + pref[i];
-  if (row < n) {
+  if (row < capacity) {
     out[row * 3] = px[i];
     out[row * 3 + 1] = py[i];
     out[row * 3 + 2] = pz[i];
   }
 }
 
-extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const double *vertices, int64_t n_vertices,
-                              const int64_t *faces, int64_t n_faces, const double voxel_size[3], const double *xs,
-                              const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
-                              const int64_t *triangle_indices, int64_t n_refs, double *out_points) {
-  if (n_points <= 0 || !out_points || !voxel_size) return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: bad arguments");
-  int ndev = dsim_device_count();
-  if (ndev <= 0) return fail(DSIM_ERR_NO_DEVICE, "no HIP device visible (need an AMD GPU with ROCm)");
-  if (device < 0 || device >= ndev) return fail(DSIM_ERR_INVALID, "device out of range");
-  HIP_TRY(hipSetDevice(device));
-  hipStream_t stream;
-  HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+/* A fill session: the device state of the _fill_mesh loop (simulations.py:505-579) for a RANGE of its threads.
+ * The reference launches _cuda_fill_mesh over n_points threads again and again - every thread draws one candidate
+ * per launch from its own RNG state - and appends the accepted points of a launch in thread order until n_points
+ * are there.  Thread t only ever needs its own state, so the threads can be split over sessions (one per GPU):
+ * each runs the same launches over its range and reports, per launch, how many of its candidates were accepted;
+ * the position of a point in the global sequence follows from those counts alone (disimpy_amd/sharding.py).
+ * dsim_fill_mesh is one session over all threads. */
+struct dsim_fill {
+  int device = 0;
+  hipStream_t stream = nullptr;
   DevMesh dm;
+  int64_t n_threads = 0;
   double *px = nullptr, *py = nullptr, *pz = nullptr;
-  uint64_t *s0 = nullptr, *s1 = nullptr, *cols = nullptr;
-  int32_t *d_col_start = nullptr;
+  uint64_t *s0 = nullptr, *s1 = nullptr;
+  int32_t *d_col_start = nullptr, *d_mstart = nullptr;
   int2 *d_col_ent = nullptr, *d_ent = nullptr, *d_mcol = nullptr, *d_ment = nullptr;
   float4 *d_ent_yz = nullptr, *d_ment_yz = nullptr;
-  int32_t *d_mstart = nullptr;
-  int rc = upload_mesh(dm, stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, 0.0);
-  auto cleanup = [&]() {
-    free_mesh(dm);
-    if (px) (void)hipFree(px);
-    if (py) (void)hipFree(py);
-    if (pz) (void)hipFree(pz);
-    if (s0) (void)hipFree(s0);
-    if (s1) (void)hipFree(s1);
-    if (cols) (void)hipFree(cols);
-    if (d_col_start) (void)hipFree(d_col_start);
-    if (d_col_ent) (void)hipFree(d_col_ent);
-    if (d_ent) (void)hipFree(d_ent);
-    if (d_ent_yz) (void)hipFree(d_ent_yz);
-    if (d_mcol) (void)hipFree(d_mcol);
-    if (d_mstart) (void)hipFree(d_mstart);
-    if (d_ment) (void)hipFree(d_ment);
-    if (d_ment_yz) (void)hipFree(d_ment_yz);
-    (void)hipStreamDestroy(stream);
-  };
-#define FILL_TRY(expr)                                                                     \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess) {                                                                \
-      cleanup();                                                                           \
-      return fail(DSIM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));             \
-    }                                                                                      \
-  } while (0)
-  if (rc) {
-    std::string keep = g_err;
-    cleanup();
-    g_err = keep;
-    return rc;
+  int32_t *d_flag = nullptr, *d_pref = nullptr;
+  int64_t *d_have = nullptr;   /* [2]: rows written so far, alternating slots */
+  int64_t *d_counts = nullptr; /* accepted points of every launch of the current run */
+  int64_t counts_cap = 0;
+  double *d_out = nullptr;     /* accepted points of the current run, in (launch, thread) order */
+  int64_t out_cap = 0;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  FillParams fp;
+  size_t lds = 0;
+  int64_t launches = 0;
+};
+
+extern "C" int dsim_fill_close(dsim_fill *fs) {
+  if (!fs) return DSIM_OK;
+  (void)hipSetDevice(fs->device);
+  if (fs->stream) (void)hipStreamSynchronize(fs->stream);
+  free_mesh(fs->dm);
+  void *ptrs[] = {fs->px, fs->py, fs->pz, fs->s0, fs->s1, fs->d_col_start, fs->d_mstart, fs->d_col_ent, fs->d_ent, fs->d_mcol, fs->d_ment,
+                  fs->d_ent_yz, fs->d_ment_yz, fs->d_flag, fs->d_pref, fs->d_have, fs->d_counts, fs->d_out, fs->d_tmp};
+  for (void *q : ptrs)
+    if (q) (void)hipFree(q);
+  if (fs->stream) (void)hipStreamDestroy(fs->stream);
+  delete fs;
+  return DSIM_OK;
+}
+
+static int fill_open_impl(dsim_fill *fs, int64_t thread_begin, int intra, uint64_t seed, const double *vertices, int64_t n_vertices,
+                          const int64_t *faces, int64_t n_faces, const double voxel_size[3], const double *xs, const double *ys,
+                          const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices, const int64_t *triangle_indices,
+                          int64_t n_refs) {
+  const int64_t n = fs->n_threads;
+  HIP_TRY(hipSetDevice(fs->device));
+  HIP_TRY(hipStreamCreateWithFlags(&fs->stream, hipStreamNonBlocking));
+  int rc = upload_mesh(fs->dm, fs->stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, 0.0);
+  if (rc) return rc;
+  HIP_TRY(hipMalloc(&fs->px, n * sizeof(double)));
+  HIP_TRY(hipMalloc(&fs->py, n * sizeof(double)));
+  HIP_TRY(hipMalloc(&fs->pz, n * sizeof(double)));
+  HIP_TRY(hipMalloc(&fs->s0, n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&fs->s1, n * sizeof(uint64_t)));
+  /* own RNG states with the same seed (simulations.py:524): thread i <- state i, whatever the range */
+  {
+    const JumpTables &jt = jump_tables();
+    uint64_t *cols = nullptr;
+    HIP_TRY(hipMalloc(&cols, jt.cols.size() * sizeof(HostRng)));
+    hipError_t e = hipMemcpyAsync(cols, jt.cols.data(), jt.cols.size() * sizeof(HostRng), hipMemcpyHostToDevice, fs->stream);
+    HostRng sd = h_seed_state(seed);
+    if (e == hipSuccess) {
+      rng_init_kernel<<<grid_for(n, 256), 256, 0, fs->stream>>>(sd.s0, sd.s1, (uint64_t)thread_begin, n, cols, jt.levels, fs->s0, fs->s1);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(fs->stream);
+    (void)hipFree(cols);
+    if (e != hipSuccess) return fail(DSIM_ERR_HIP, "fill: RNG seeding failed: %s", hipGetErrorString(e));
   }
-  FILL_TRY(hipMalloc(&px, n_points * sizeof(double)));
-  FILL_TRY(hipMalloc(&py, n_points * sizeof(double)));
-  FILL_TRY(hipMalloc(&pz, n_points * sizeof(double)));
-  FILL_TRY(hipMalloc(&s0, n_points * sizeof(uint64_t)));
-  FILL_TRY(hipMalloc(&s1, n_points * sizeof(uint64_t)));
-  /* own RNG states with the same seed (simulations.py:524): thread i <- state i */
-  const JumpTables &jt = jump_tables();
-  FILL_TRY(hipMalloc(&cols, jt.cols.size() * sizeof(HostRng)));
-  FILL_TRY(hipMemcpyAsync(cols, jt.cols.data(), jt.cols.size() * sizeof(HostRng), hipMemcpyHostToDevice, stream));
-  HostRng sd = h_seed_state(seed);
-  const int grid = grid_for(n_points, 256);
-  rng_init_kernel<<<grid, 256, 0, stream>>>(sd.s0, sd.s1, 0, n_points, cols, jt.levels, s0, s1);
-  FILL_TRY(hipGetLastError());
   /* (y, z) extent of every triangle, float32 rounded outward by three ulps: cull box of the
    * +x rays of fill_mesh_kernel */
   std::vector<float4> h_tri_yz((size_t)n_faces);
@@ -1672,7 +1741,7 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   /* the fill kernel's index (see FillParams): per (y, z) column the non-empty subvoxels in ascending x, and per
    * list entry the triangle, where it was last met in the column, and its (y, z) extent */
   {
-    const int nx = dm.nx, ny = dm.ny, nz = dm.nz;
+    const int nx = fs->dm.nx, ny = fs->dm.ny, nz = fs->dm.nz;
     std::vector<int32_t> col_start((size_t)ny * nz + 1, 0), last_x((size_t)std::max<int64_t>(n_faces, 1), -1), touched;
     std::vector<int2> col_ent, ent;
     std::vector<float4> ent_yz;
@@ -1687,7 +1756,6 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
           const int64_t lo = subvoxel_indices[sv * 2], hi = subvoxel_indices[sv * 2 + 1];
           if (hi <= lo) continue;
           if (lo < 0 || hi > n_refs) {
-            cleanup();
             return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: subvoxel %lld lists entries [%lld, %lld) of %lld", (long long)sv, (long long)lo,
                         (long long)hi, (long long)n_refs);
           }
@@ -1695,7 +1763,6 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
           for (int64_t i = lo; i < hi; i++) {
             const int64_t ti = triangle_indices[i];
             if (ti < 0 || ti >= n_faces) {
-              cleanup();
               return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: list entry %lld names triangle %lld of %lld", (long long)i, (long long)ti,
                           (long long)n_faces);
             }
@@ -1732,7 +1799,7 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
           const int n_e = e1 - e0;
           const int G = n_e <= 8 ? 1 : (n_e <= 48 ? 4 : (n_e <= 400 ? 8 : 16));
           buckets.assign((size_t)G * G, {});
-          const double sy = (double)G * dm.inv_h[1], sz = (double)G * dm.inv_h[2];
+          const double sy = (double)G * fs->dm.inv_h[1], sz = (double)G * fs->dm.inv_h[2];
           for (int i = e1 - 1; i >= e0; i--) { /* descending x (ascending order reversed) */
             const float4 q = ent_yz[i];
             auto cell = [&](double v, double o, double sc, double d) {
@@ -1760,97 +1827,146 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
         ment_yz.push_back(make_float4(0, 0, 0, 0));
       }
     }
-    FILL_TRY(hipMalloc(&d_mcol, mcol.size() * sizeof(int2)));
-    FILL_TRY(hipMalloc(&d_mstart, mstart.size() * sizeof(int32_t)));
-    FILL_TRY(hipMalloc(&d_ment, ment.size() * sizeof(int2)));
-    FILL_TRY(hipMalloc(&d_ment_yz, ment_yz.size() * sizeof(float4)));
-    FILL_TRY(hipMemcpy(d_mcol, mcol.data(), mcol.size() * sizeof(int2), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_mstart, mstart.data(), mstart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_ment, ment.data(), ment.size() * sizeof(int2), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_ment_yz, ment_yz.data(), ment_yz.size() * sizeof(float4), hipMemcpyHostToDevice));
-    FILL_TRY(hipMalloc(&d_col_start, col_start.size() * sizeof(int32_t)));
-    FILL_TRY(hipMalloc(&d_col_ent, col_ent.size() * sizeof(int2)));
-    FILL_TRY(hipMalloc(&d_ent, ent.size() * sizeof(int2)));
-    FILL_TRY(hipMalloc(&d_ent_yz, ent_yz.size() * sizeof(float4)));
-    FILL_TRY(hipMemcpy(d_col_start, col_start.data(), col_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_col_ent, col_ent.data(), col_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(int2), hipMemcpyHostToDevice));
-    FILL_TRY(hipMemcpy(d_ent_yz, ent_yz.data(), ent_yz.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&fs->d_mcol, mcol.size() * sizeof(int2)));
+    HIP_TRY(hipMalloc(&fs->d_mstart, mstart.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&fs->d_ment, ment.size() * sizeof(int2)));
+    HIP_TRY(hipMalloc(&fs->d_ment_yz, ment_yz.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(fs->d_mcol, mcol.data(), mcol.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fs->d_mstart, mstart.data(), mstart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fs->d_ment, ment.data(), ment.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fs->d_ment_yz, ment_yz.data(), ment_yz.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&fs->d_col_start, col_start.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&fs->d_col_ent, col_ent.size() * sizeof(int2)));
+    HIP_TRY(hipMalloc(&fs->d_ent, ent.size() * sizeof(int2)));
+    HIP_TRY(hipMalloc(&fs->d_ent_yz, ent_yz.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(fs->d_col_start, col_start.data(), col_start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fs->d_col_ent, col_ent.data(), col_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fs->d_ent, ent.data(), ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fs->d_ent_yz, ent_yz.data(), ent_yz.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
-  FillParams fp;
-  fp.col_start = d_col_start;
-  fp.col_ent = d_col_ent;
-  fp.ent = d_ent;
-  fp.ent_yz = d_ent_yz;
-  fp.mcol = d_mcol;
-  fp.mstart = d_mstart;
-  fp.ment = d_ment;
-  fp.ment_yz = d_ment_yz;
-  fp.n_points = n_points;
-  fp.px = px;
-  fp.py = py;
-  fp.pz = pz;
-  fp.s0 = s0;
-  fp.s1 = s1;
+  FillParams &fp = fs->fp;
+  fp.col_start = fs->d_col_start;
+  fp.col_ent = fs->d_col_ent;
+  fp.ent = fs->d_ent;
+  fp.ent_yz = fs->d_ent_yz;
+  fp.mcol = fs->d_mcol;
+  fp.mstart = fs->d_mstart;
+  fp.ment = fs->d_ment;
+  fp.ment_yz = fs->d_ment_yz;
+  fp.n_points = n;
+  fp.px = fs->px;
+  fp.py = fs->py;
+  fp.pz = fs->pz;
+  fp.s0 = fs->s0;
+  fp.s1 = fs->s1;
   fp.intra = intra ? 1 : 0;
   for (int k = 0; k < 3; k++) fp.voxel[k] = voxel_size[k];
-  fp.mesh = mesh_dev(dm);
-  const size_t lds = (size_t)(dm.nx + dm.ny + dm.nz + 3) * sizeof(double);
-  /* Accepted points are compacted ON THE DEVICE in thread order (simulations.py:573-576 keeps the
-   * finite rows of every launch in order): flags -> exclusive scan -> scatter into the output at
-   * offset `have`; only the running count crosses PCIe per launch. */
-  if (n_points >= (int64_t)INT32_MAX) {
-    cleanup();
-    return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: too many points");
+  fp.mesh = mesh_dev(fs->dm);
+  fs->lds = (size_t)(fs->dm.nx + fs->dm.ny + fs->dm.nz + 3) * sizeof(double);
+  HIP_TRY(hipMalloc(&fs->d_flag, n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&fs->d_pref, n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&fs->d_have, 2 * sizeof(int64_t)));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, fs->tmp_bytes, fs->d_flag, fs->d_pref, (int)n, fs->stream));
+  HIP_TRY(hipMalloc(&fs->d_tmp, fs->tmp_bytes));
+  fp.flag = fs->d_flag;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_fill_open(dsim_fill **out, int device, int64_t thread_begin, int64_t thread_end, int intra, uint64_t seed,
+                              const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double voxel_size[3],
+                              const double *xs, const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                              const int64_t *triangle_indices, int64_t n_refs) {
+  if (!out) return fail(DSIM_ERR_INVALID, "dsim_fill_open: out is NULL");
+  *out = nullptr;
+  if (thread_begin < 0 || thread_end <= thread_begin || !voxel_size) return fail(DSIM_ERR_INVALID, "dsim_fill_open: bad thread range");
+  if (thread_end - thread_begin >= (int64_t)INT32_MAX || ((uint64_t)thread_end >> 47)) return fail(DSIM_ERR_INVALID, "dsim_fill_open: too many threads");
+  int ndev = dsim_device_count();
+  if (ndev <= 0) return fail(DSIM_ERR_NO_DEVICE, "no HIP device visible (need an AMD GPU with ROCm)");
+  if (device < 0 || device >= ndev) return fail(DSIM_ERR_INVALID, "device out of range");
+  dsim_fill *fs = new dsim_fill();
+  fs->device = device;
+  fs->n_threads = thread_end - thread_begin;
+  int rc = fill_open_impl(fs, thread_begin, intra, seed, vertices, n_vertices, faces, n_faces, voxel_size, xs, ys, zs, n_sv, subvoxel_indices,
+                          triangle_indices, n_refs);
+  if (rc) {
+    std::string keep = g_err;
+    dsim_fill_close(fs);
+    g_err = keep;
+    return rc;
   }
-  int32_t *d_flag = nullptr, *d_pref = nullptr;
-  int64_t *d_have = nullptr;
-  double *d_out = nullptr;
-  void *d_tmp = nullptr;
-  size_t tmp_bytes = 0;
-  auto cleanup2 = [&]() {
-    if (d_flag) (void)hipFree(d_flag);
-    if (d_pref) (void)hipFree(d_pref);
-    if (d_have) (void)hipFree(d_have);
-    if (d_out) (void)hipFree(d_out);
-    if (d_tmp) (void)hipFree(d_tmp);
-    cleanup();
-  };
-#define FILL_TRY2(expr)                                                                    \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess) {                                                                \
-      cleanup2();                                                                          \
-      return fail(DSIM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));             \
-    }                                                                                      \
-  } while (0)
-  FILL_TRY2(hipMalloc(&d_flag, n_points * sizeof(int32_t)));
-  FILL_TRY2(hipMalloc(&d_pref, n_points * sizeof(int32_t)));
-  FILL_TRY2(hipMalloc(&d_have, 2 * sizeof(int64_t)));
-  FILL_TRY2(hipMalloc(&d_out, (size_t)n_points * 3 * sizeof(double)));
-  FILL_TRY2(hipMemsetAsync(d_have, 0, 2 * sizeof(int64_t), stream));
-  FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
-  FILL_TRY2(hipMalloc(&d_tmp, tmp_bytes));
-  fp.flag = d_flag;
-  /* The running count is read back after a BATCH of launches: a launch past the n-th accepted point only
-   * produces rows that the scatter drops (and advances RNG states nobody reads again), so running a few too many
-   * is harmless; the batch is sized from the acceptance rate seen so far so that the stream is not drained
-   * after each of the ~1/rate launches a thin structure needs (the neuron: ~4000). */
+  *out = fs;
+  return DSIM_OK;
+}
+
+/* n_launches more launches over the session's threads.  counts[l] = accepted candidates of launch l; their points,
+ * in (launch, thread) order, go to points[(row, 3)] - at most `capacity` rows, the rest is dropped (the caller sizes
+ * its batches so that nothing it needs is; *n_rows = rows written).  Accepted points are compacted ON THE DEVICE in
+ * thread order (simulations.py:573-576 keeps the finite rows of every launch in order): flags -> exclusive scan ->
+ * scatter behind the rows already there; only counts and rows cross PCIe, once per call. */
+extern "C" int dsim_fill_run(dsim_fill *fs, int64_t n_launches, int64_t *counts, double *points, int64_t capacity, int64_t *n_rows) {
+  if (!fs || n_launches <= 0 || !counts || capacity < 0 || (capacity > 0 && !points)) return fail(DSIM_ERR_INVALID, "dsim_fill_run: bad arguments");
+  HIP_TRY(hipSetDevice(fs->device));
+  if (fs->launches + n_launches > 1000000) return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
+  if (fs->counts_cap < n_launches) {
+    if (fs->d_counts) HIP_TRY(hipFree(fs->d_counts));
+    fs->d_counts = nullptr;
+    HIP_TRY(hipMalloc(&fs->d_counts, n_launches * sizeof(int64_t)));
+    fs->counts_cap = n_launches;
+  }
+  const int64_t cap = std::max<int64_t>(capacity, 1);
+  if (fs->out_cap < cap) {
+    if (fs->d_out) HIP_TRY(hipFree(fs->d_out));
+    fs->d_out = nullptr;
+    HIP_TRY(hipMalloc(&fs->d_out, (size_t)cap * 3 * sizeof(double)));
+    fs->out_cap = cap;
+  }
+  HIP_TRY(hipMemsetAsync(fs->d_have, 0, 2 * sizeof(int64_t), fs->stream));
+  const int64_t n = fs->n_threads;
+  const int grid = grid_for(n, 256);
+  for (int64_t k = 0; k < n_launches; k++) {
+    fill_mesh_kernel<<<grid, 256, fs->lds, fs->stream>>>(fs->fp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(fs->d_tmp, fs->tmp_bytes, fs->d_flag, fs->d_pref, (int)n, fs->stream));
+    fill_scatter_kernel<<<grid, 256, 0, fs->stream>>>(fs->px, fs->py, fs->pz, fs->d_flag, fs->d_pref, n, capacity, fs->d_have + (k & 1),
+                                                      fs->d_have + ((k + 1) & 1), fs->d_counts + k, fs->d_out);
+    HIP_TRY(hipGetLastError());
+  }
+  fs->launches += n_launches;
+  int64_t have = 0;
+  HIP_TRY(hipMemcpyAsync(&have, fs->d_have + (n_launches & 1), sizeof(int64_t), hipMemcpyDeviceToHost, fs->stream));
+  HIP_TRY(hipMemcpyAsync(counts, fs->d_counts, n_launches * sizeof(int64_t), hipMemcpyDeviceToHost, fs->stream));
+  HIP_TRY(hipStreamSynchronize(fs->stream));
+  const int64_t rows = std::min(have, capacity);
+  if (rows > 0) {
+    HIP_TRY(hipMemcpyAsync(points, fs->d_out, (size_t)rows * 3 * sizeof(double), hipMemcpyDeviceToHost, fs->stream));
+    HIP_TRY(hipStreamSynchronize(fs->stream));
+  }
+  if (n_rows) *n_rows = rows;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const double *vertices, int64_t n_vertices,
+                              const int64_t *faces, int64_t n_faces, const double voxel_size[3], const double *xs,
+                              const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                              const int64_t *triangle_indices, int64_t n_refs, double *out_points) {
+  if (n_points <= 0 || !out_points || !voxel_size) return fail(DSIM_ERR_INVALID, "dsim_fill_mesh: bad arguments");
+  dsim_fill *fs = nullptr;
+  int rc = dsim_fill_open(&fs, device, 0, n_points, intra, seed, vertices, n_vertices, faces, n_faces, voxel_size, xs, ys, zs, n_sv,
+                          subvoxel_indices, triangle_indices, n_refs);
+  if (rc) return rc;
+  /* The running count comes back after a BATCH of launches: a launch past the n-th accepted point only produces
+   * rows that are dropped (and advances RNG states nobody reads again), so running a few too many is harmless;
+   * the batch is sized from the acceptance rate seen so far so that the stream is not drained after each of the
+   * ~1/rate launches a thin structure needs (the neuron: ~4000). */
   int64_t have = 0, launches = 0, batch = 1;
-  while (have < n_points) {
-    for (int64_t k = 0; k < batch; k++) {
-      if (++launches > 1000000) {
-        cleanup2();
-        return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
-      }
-      fill_mesh_kernel<<<grid, 256, lds, stream>>>(fp);
-      FILL_TRY2(hipGetLastError());
-      FILL_TRY2(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flag, d_pref, (int)n_points, stream));
-      fill_scatter_kernel<<<grid, 256, 0, stream>>>(px, py, pz, d_flag, d_pref, n_points, d_have + (launches & 1), d_have + ((launches + 1) & 1), d_out);
-      FILL_TRY2(hipGetLastError());
-    }
-    FILL_TRY2(hipMemcpyAsync(&have, d_have + ((launches + 1) & 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FILL_TRY2(hipStreamSynchronize(stream));
+  std::vector<int64_t> counts;
+  while (have < n_points && rc == DSIM_OK) {
+    counts.assign((size_t)batch, 0);
+    int64_t rows = 0;
+    rc = dsim_fill_run(fs, batch, counts.data(), out_points + have * 3, n_points - have, &rows);
+    if (rc) break;
+    launches += batch;
+    have += rows;
     if (have > 0 && have < n_points) {
       const double per_launch = (double)have / (double)launches;
       const double left = (double)(n_points - have) / per_launch;
@@ -1859,12 +1975,10 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
       batch = std::min<int64_t>(batch * 2, 64);
     }
   }
-  FILL_TRY2(hipMemcpyAsync(out_points, d_out, (size_t)n_points * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
-  FILL_TRY2(hipStreamSynchronize(stream));
-  cleanup2();
-  return DSIM_OK;
-#undef FILL_TRY2
-#undef FILL_TRY
+  const std::string keep = g_err;
+  dsim_fill_close(fs);
+  g_err = keep;
+  return rc;
 }
 
 /* -------------------------------------------- mesh subdivision (host only) --- */

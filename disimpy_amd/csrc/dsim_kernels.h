@@ -865,6 +865,16 @@ __global__ __launch_bounds__(64) void signal_final_kernel(const double *partial,
   }
 }
 
+/* all_signals (simulations.py:1414-1417): out[e] = cos(phase[first + e]) for the elements [first, first + count) of
+ * the flattened (M, n) phase matrix, NaN where the walker's iter_exc flag is set */
+__global__ __launch_bounds__(256) void all_signals_kernel(const double *phase, const uint8_t *exc, int64_t n, int64_t first,
+                                                          int64_t count, double *out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const int64_t i = (first + e) % n;
+  out[e] = exc[i] != 0 ? DS_NAN : cos(phase[first + e]);
+}
+
 /* ---- layout conversion ---------------------------------------------------------- */
 
 __global__ void aos_to_soa_kernel(const double *aos, int64_t n, double *x, double *y, double *z) {

@@ -45,6 +45,91 @@ def reduce_signal(cos_sum, sin_sum, n_exceeded, dist=None, device=None):
     return out[:M], out[M : 2 * M], int(round(out[2 * M]))
 
 
+def _all_gather(arr, dist, device=None):
+    """all-gather of equally shaped numpy arrays -> list, one per rank"""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    on_gpu = dist.get_backend() == "nccl"
+    if on_gpu:
+        t = t.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().numpy() for o in out]
+
+
+def fill_mesh_sharded(n_points, open_session, dist=None, device=None, walker_range=None):
+    """``simulations._fill_mesh`` with the launches' threads split over the ranks (disimpy/simulations.py:505-579).
+
+    The reference launches one candidate per thread again and again and appends the accepted candidates of a launch
+    in thread order until ``n_points`` are there.  Thread t draws from RNG state t whatever the split, so rank r runs
+    the same launches over ITS range of threads (``open_session(thread_begin, thread_end)`` -> an object with
+    ``run(n_launches, capacity) -> (counts, points)`` and ``close()``: disimpy_amd._lib.FillSession) and only the
+    per-launch counts are exchanged - one small all-gather per batch of launches - to place every accepted point in
+    the global sequence; at the end one all-gather hands the rows out.  The result is the single-process sequence bit
+    for bit; the device work per rank is 1 / world_size of it.
+
+    Returns the rows ``walker_range`` = [a, b) of the sequence (default: this rank's walker shard)."""
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    a, b = walker_range if walker_range is not None else shard_range(n_points, rank, world)
+    t0, t1 = shard_range(n_points, rank, world)  # threads of this rank (the same balanced split as the walkers)
+    sess = open_session(t0, t1) if t1 > t0 else None
+    try:
+        have, launches, batch = 0, 0, 1
+        rows_kept, pts_kept = [], []
+        while have < n_points:
+            # a rank's accepted points beyond the (n_points - have)-th cannot be needed; with an estimate of the rate
+            # the buffer is kept small (8x the expectation: an overflow would have to be reported, never dropped)
+            cap = min(n_points - have, (t1 - t0) * batch)
+            if launches and have:
+                cap = min(cap, int(8.0 * have / launches * batch * (t1 - t0) / n_points) + 100_000)
+            if sess is not None:
+                counts, pts = sess.run(batch, cap)
+                if int(counts.sum()) > len(pts) and len(pts) < n_points - have:
+                    raise RuntimeError("fill_mesh_sharded: %d accepted points in one batch overflow the buffer of %d" % (counts.sum(), cap))
+            else:
+                counts, pts = np.zeros(batch, dtype=np.int64), np.zeros((0, 3))
+            all_counts = np.stack(_all_gather(counts, dist, device)) if world > 1 else counts[None, :]
+            per_launch = all_counts.sum(axis=0)
+            launch_base = have + np.concatenate([[0], np.cumsum(per_launch)[:-1]])
+            mine = launch_base + all_counts[:rank].sum(axis=0)  # global row of my first point of every launch
+            rows = np.concatenate([m + np.arange(c) for m, c in zip(mine, counts)]) if counts.sum() else np.zeros(0, dtype=np.int64)
+            rows = rows[: len(pts)]
+            keep = rows < n_points
+            rows_kept.append(rows[keep].astype(np.int64))
+            pts_kept.append(pts[: len(rows)][keep])
+            launches += batch
+            have += int(per_launch.sum())
+            if launches > 1_000_000:
+                raise RuntimeError("fill_mesh: no progress after 1000000 launches (is the surface closed?)")
+            if 0 < have < n_points:  # the same batch rule as the library's own loop, from globally known numbers
+                left = (n_points - have) / (have / launches)
+                batch = int(min(64.0, max(1.0, np.floor(left * 0.9))))
+            elif have == 0:
+                batch = min(batch * 2, 64)
+    finally:
+        if sess is not None:
+            sess.close()
+    rows = np.concatenate(rows_kept) if rows_kept else np.zeros(0, dtype=np.int64)
+    pts = np.concatenate(pts_kept) if pts_kept else np.zeros((0, 3))
+    out = np.empty((b - a, 3))
+    if world == 1:
+        sel = (rows >= a) & (rows < b)
+        out[rows[sel] - a] = pts[sel]
+        return out
+    sizes = [int(x[0]) for x in _all_gather(np.array([len(rows)], dtype=np.int64), dist, device)]
+    width = max(sizes + [1])
+    pad_rows = np.full(width, -1, dtype=np.int64)
+    pad_rows[: len(rows)] = rows
+    pad_pts = np.zeros((width, 3))
+    pad_pts[: len(rows)] = pts
+    for r_rows, r_pts in zip(_all_gather(pad_rows, dist, device), _all_gather(pad_pts, dist, device)):
+        sel = (r_rows >= a) & (r_rows < b)
+        out[r_rows[sel] - a] = r_pts[sel]
+    return out
+
+
 def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123, quiet=True, max_iter=int(1e3),
                        epsilon=1e-13, dist=None, device=None):
     """``simulations.simulation`` with the walkers split over the ranks of the
@@ -57,11 +142,13 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
     simulations._validate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, 128, max_iter)
     np.random.seed(seed)
     a, b = shard_range(n_walkers, rank, world)
-    if b == a:  # more ranks than walkers: nothing to simulate here, but the collective still needs this rank
+    if b == a:  # more ranks than walkers: nothing to simulate here, but the collectives still need this rank
+        if world > 1 and substrate.type == "mesh" and isinstance(substrate.init_pos, str) and substrate.init_pos in ("intra", "extra"):
+            simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (a, b), dist=dist)  # the shared fill
         M = gradient.shape[0]
         c, s, nexc = reduce_signal(np.zeros(M), np.zeros(M), 0, dist, device)
         return c
     res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, max_iter, epsilon,
-                                device=device or 0, walker_range=(a, b))
+                                device=device or 0, walker_range=(a, b), dist=dist if world > 1 else None)
     c, s, nexc = reduce_signal(res["cos"], res["sin"], res["n_exceeded"], dist, device)
     return c

@@ -105,14 +105,24 @@ def _strip_wall_triangles(substrate):
     return vertices, faces, np.delete(tri, deleted), svi
 
 
-def _fill_mesh(n_points, substrate, intra, seed, cuda_bs=128, device=0):
+def _fill_mesh(n_points, substrate, intra, seed, cuda_bs=128, device=0, dist=None, walker_range=None):
     """Sample points uniformly inside (``intra``) or outside the closed surface of
-    a triangular mesh on the GPU (disimpy/simulations.py:505-579)."""
+    a triangular mesh on the GPU (disimpy/simulations.py:505-579).  With an initialised
+    process group ``dist`` the launches' threads are split over the ranks
+    (sharding.fill_mesh_sharded) and only the rows ``walker_range`` come back."""
     if substrate.periodic:
         vertices, faces = substrate.vertices, substrate.faces
         tri, svi = substrate.triangle_indices, substrate.subvoxel_indices
     else:
         vertices, faces, tri, svi = _strip_wall_triangles(substrate)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        from . import sharding
+
+        def open_session(t0, t1):
+            return _lib.FillSession(t0, t1, intra, seed, vertices, faces, substrate.voxel_size, substrate.xs, substrate.ys,
+                                    substrate.zs, substrate.n_sv, svi, tri, device=device)
+
+        return sharding.fill_mesh_sharded(n_points, open_session, dist, device, walker_range)
     return _lib.fill_mesh(
         n_points, intra, seed, vertices, faces, substrate.voxel_size, substrate.xs, substrate.ys, substrate.zs,
         substrate.n_sv, svi, tri, device=device,
@@ -194,7 +204,7 @@ def _validate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         raise ValueError("Incorrect value (%s) for max_iter" % max_iter)
 
 
-def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=None):
+def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=None, dist=None):
     """Initial positions of the walkers [a, b) = ``walker_range`` (default: all) and the
     substrate's rotation frames.  Returns (positions (b - a, 3) or None for zeros, frames).
 
@@ -235,6 +245,9 @@ def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=N
             print("Calculating initial positions")
         if substrate.init_pos == "uniform":
             pos = (np.random.random((b, 3)) * substrate.voxel_size)[a:b]
+        elif dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            # the device fill is shared by the ranks (threads of every launch split, sharding.fill_mesh_sharded)
+            pos = _fill_mesh(n_walkers, substrate, substrate.init_pos == "intra", seed, device=device, dist=dist, walker_range=(a, b))
         elif substrate.init_pos == "intra":
             pos = _fill_mesh(n_walkers, substrate, True, seed, device=device)[a:b]
         else:
@@ -260,7 +273,7 @@ def _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1):
 
 
 def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon, device=0,
-              walker_range=None, need_phases=False, need_positions=False):
+              walker_range=None, need_phases=False, need_positions=False, dist=None):
     """Run walkers [a, b) = ``walker_range`` (default: all) on one GPU.
 
     Returns a dict with the device-reduced signal sums and, on request,
@@ -275,7 +288,7 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         print("Number of steps = %s" % n_t)
         print("Step length = %s m" % step_l)
         print("Step duration = %s s" % dt)
-    positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b))
+    positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b), dist=dist)
     with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a) as sim:
         sim.rng_init_device(seed)
         if positions is not None:
@@ -311,9 +324,9 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
                 sys.stdout.flush()
         out = {"device_ms": ms_total, "range": (a, b)}
         out["cos"], out["sin"], out["n_exceeded"] = sim.signal()
-        out["iter_exc"] = sim.iter_exc() if (out["n_exceeded"] or need_phases) else np.zeros(b - a, dtype=bool)
-        if need_phases:
-            out["phases"] = sim.phases()
+        out["iter_exc"] = sim.iter_exc() if out["n_exceeded"] else np.zeros(b - a, dtype=bool)
+        if need_phases:  # all_signals: real(exp(1j * phases)) with the NaN mask, evaluated on the device (:1414-1417)
+            out["all_signals"] = sim.all_signals()
         if need_positions:
             out["positions"] = sim.positions()
     return out
@@ -394,9 +407,7 @@ def simulation(
             + "check algorithm for walkers %s" % np.where(iter_exc)[0]
         )
     if all_signals:
-        phases = res["phases"]
-        phases[:, np.where(iter_exc)[0]] = np.nan
-        signals = np.real(np.exp(1j * phases))
+        signals = res["all_signals"]
     else:
         signals = res["cos"]
     if not quiet:

@@ -19,12 +19,13 @@
  * Hard limits (every one fails loudly with DSIM_ERR_INVALID / DSIM_ERR_STATE and a message,
  * none silently changes results):
  *   - walker indices: first_walker + n_walkers < 2^47 (depth of the RNG jump tables);
- *   - mesh: n_faces, n_refs and prod(n_sv) < 2^31, every n_sv[k] in [1, 4096]; the
- *     wavefront-cooperative traversal packs subvoxel coordinates in 10 bits, so with an
- *     n_sv[k] > 1024 every pass is done by the slower serial per-walker path (same results),
- *     and triangle numbers and list positions in 24 bits each, so a mesh with 2^24 or more faces
- *     or list entries runs the per-lane traversal (mesh_traversal 1; same results);
- *     the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
+ *   - mesh: n_faces, n_refs and prod(n_sv) < 2^31, every n_sv[k] in [1, 4096]; the wavefront-cooperative
+ *     traversal (the default, mesh_traversal 2) assumes the reference's own subvoxel grid, xs = linspace(0, L, n + 1)
+ *     on every axis (substrates.py:506-508): any other boundaries handed in here are walked by the per-lane
+ *     traversal (mesh_traversal 1; same results, checked against the boundary values themselves).  A walker whose
+ *     segment reaches more than 31 periodic images away from the voxel, spans more than 64 runs of fine cells or meets
+ *     two different triangles at bit-equal distances is redone by its own lane in the reference's order (same
+ *     results); the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
  *     i.e. n_sv[0] + n_sv[1] + n_sv[2] below about 14 000;
  *   - spatial re-sorting of the walker slots (mesh substrates) needs 4096 <= n_walkers < 2^31
  *     per handle; outside that range the run proceeds unsorted (slower, same results);
@@ -34,6 +35,15 @@
  *   - dsim_fill_mesh: n_points < 2^31, and a sample that meets 1000 distinct triangles is
  *     abandoned like in the reference (simulations.py:478-479);
  *   - gradient: M >= 1, T >= 1, T * M * 32 bytes of device memory for the re-laid-out waveform.
+ *
+ * Environment.  The library reads three variables, all of them tuning switches for measurement runs - results never
+ * depend on them (the GPU parity tests run with and without):
+ *   DSIM_GROUPS=1..4      walker groups (streams) of a mesh run with per-walker clocks; default 2 from 2^18 walkers;
+ *   DSIM_SORT_BITS=6..24  log2 of the Morton bins of the walker re-sort; default 18;
+ *   DSIM_MICRO=t1,t2,t3,t4,min_cell  thresholds of the fine grid (list length -> cells per subvoxel) and the smallest
+ *                         cell in step lengths; default 2,4,16,2^30,1.5.
+ * The Python binding adds DSIM_LIB=<path> (disimpy_amd/_lib.py): load another build of this library, e.g. an older
+ * kernel for a same-box A/B; every symbol of this header must be there, or loading fails.
  */
 #ifndef DSIM_H
 #define DSIM_H
@@ -129,6 +139,11 @@ int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_
 int dsim_get_positions(dsim_handle h, double *positions_aos);        /* (n_walkers,3), :1212, :1426 */
 int dsim_get_phases(dsim_handle h, double *phases);                  /* (M,n_walkers), :1415          */
 int dsim_get_iter_exc(dsim_handle h, uint8_t *iter_exc);             /* (n_walkers,), :1406           */
+/* all_signals=True (simulations.py:1414-1417): signals[m, i] = real(exp(1j * phases[m, i])) = cos(phases[m, i]), NaN for
+ * walkers with iter_exc set - evaluated on the device and handed over in blocks through pinned staging buffers on a
+ * copy stream of its own (the reference copies the whole (M, N) phase matrix to the host and takes a complex
+ * exponential of it on one core). */
+int dsim_get_all_signals(dsim_handle h, double *signals);            /* (M,n_walkers)                 */
 int dsim_get_rng_states(dsim_handle h, uint64_t *states);            /* n_walkers pairs               */
 
 /* Initial positions inside ('intra' != 0) or outside the surface: the whole
@@ -142,6 +157,22 @@ int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const
                    const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                    const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs,
                    double *out_points);
+
+/* The same loop for a RANGE of its threads, so that the GPUs of a node share it (disimpy_amd/sharding.py,
+ * fill_mesh_sharded).  Thread t draws one candidate per launch from RNG state t whatever the range, and the reference
+ * appends the accepted candidates of a launch in thread order (simulations.py:560-579): a session runs launches over
+ * threads [thread_begin, thread_end) and reports per launch how many of them were accepted plus the accepted points in
+ * (launch, thread) order; where a point stands in the global sequence follows from the counts of all sessions.
+ * dsim_fill_mesh == one session over threads [0, n_points). */
+typedef struct dsim_fill dsim_fill;
+int dsim_fill_open(dsim_fill **out, int device, int64_t thread_begin, int64_t thread_end, int intra, uint64_t seed,
+                   const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double voxel_size[3],
+                   const double *xs, const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                   const int64_t *triangle_indices, int64_t n_refs);
+/* n_launches further launches: counts[n_launches], points[(rows, 3)] with at most `capacity` rows (further accepted
+ * points are dropped), *n_rows = rows written */
+int dsim_fill_run(dsim_fill *session, int64_t n_launches, int64_t *counts, double *points, int64_t capacity, int64_t *n_rows);
+int dsim_fill_close(dsim_fill *session);
 
 /* Voxelised triangle index on the host (substrates.py:467-536,
  * _mesh_space_subdivision; the boundaries xs/ys/zs of :506-508 are passed in).

@@ -15,8 +15,29 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_SPAWNER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tests that need extra processes on the GPU box (two product ranks over gloo) fork them from a fork server, and the
+    # server is started HERE - before any test has initialised the GPU: on this pool a process that has touched HIP must
+    # not fork+exec.  The server itself never touches the GPU; its children start clean.
+    global _SPAWNER
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        import multiprocessing as mp
+        from multiprocessing import forkserver
+
+        _SPAWNER = mp.get_context("forkserver")
+        _SPAWNER.set_forkserver_preload(["numpy", "torch"])
+        forkserver.ensure_running()
+
+
+@pytest.fixture(scope="session")
+def rank_spawner():
+    if _SPAWNER is None:
+        pytest.skip("needs the fork server that conftest starts for `-m gpu` sessions")
+    return _SPAWNER
 
 
 def golden(name):

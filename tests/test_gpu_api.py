@@ -327,3 +327,45 @@ def test_c5_scale_neuron_containment(api):
         s, pos = simulations.simulation(int(1e5), D, g[:2], dt, sub, final_pos=True, quiet=True)
     assert np.all(np.max(pos, axis=0) < sub.voxel_size) and np.all(np.min(pos, axis=0) > 0)
     assert np.all(np.isfinite(s)) and np.all(s / 1e5 <= 1.0) and s[0] / 1e5 > 0.99  # b = 1 s/m^2: no attenuation
+
+
+def test_all_signals_on_the_device_equal_the_host_formula(api, oracle_exact):
+    """all_signals=True: cos(phase) with the NaN mask evaluated on the device and handed over in 32 MB blocks
+    (dsim_get_all_signals) against np.real(np.exp(1j * phases)) of the ORACLE's phases (simulations.py:1414-1417);
+    5e5 walkers x 20 measurements = 80 MB: three blocks through the double-buffered copy."""
+    from disimpy_amd import _lib
+    from oracle.oracle import SPHERE
+
+    gradients, simulations, substrates = api
+    o = oracle_exact
+    n, M, T = 500_000, 20, 6
+    rng = np.random.RandomState(3)
+    g = rng.normal(size=(M, T, 3)) * 0.5
+    dt, radius = 2e-5, 2e-6  # step length 0.49 um: a few per cent of the walkers need more than two passes
+    step_l = float(np.sqrt(6 * D * dt))
+    pos0 = np.ascontiguousarray(simulations._fill_sphere(n, radius, simulations._host_rng(123)))
+    with _lib.Sim(n, g, dt, step_l) as sim:
+        sim.rng_init_device(123)
+        sim.set_positions(pos0)
+        sim.run_sphere(radius, 2, 1e-13, 0, T)  # max_iter 2: some walkers exceed it
+        got = sim.all_signals()
+        exc = sim.iter_exc()
+        ph_dev = sim.phases()
+    st = o.rng_states(n, 123)
+    p = pos0.copy()
+    ph, exc_o, _ = o.run(o.geom(SPHERE, radius=radius, max_iter=2), g, dt, step_l, p, st, n_threads=8)
+    npt.assert_array_equal(exc, exc_o.astype(bool))
+    npt.assert_array_equal(ph_dev, ph)
+    assert 10 < exc.sum() < n - 10  # both kinds of walkers
+    want = np.real(np.exp(1j * ph))
+    want[:, exc] = np.nan
+    assert got.shape == (M, n)
+    npt.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.abs(got[ok] - want[ok]).max() <= 4.5e-16  # device cos vs glibc cos: within 2 ulp of 1
+    # and through the Python API
+    sub = substrates.sphere(radius)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        api_out = simulations.simulation(1000, D, g, dt, sub, quiet=True, max_iter=2, all_signals=True)
+    npt.assert_array_equal(api_out, got[:, :1000])

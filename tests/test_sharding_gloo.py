@@ -132,3 +132,70 @@ def test_rank_with_an_empty_shard_still_joins_the_reduction():
     for g in got[1:]:
         np.testing.assert_array_equal(g[2], got[0][2])
     assert np.all(np.abs(got[0][2]) <= n)
+
+
+class _FakeFill:
+    """Stand-in for disimpy_amd._lib.FillSession on the CPU: thread t of launch l accepts with probability p, decided and
+    placed by a hash of (t, l) - the same for every split of the threads, as on the device (thread t <- RNG state t)."""
+
+    def __init__(self, t0, t1, p):
+        self.t, self.launch, self.p = np.arange(t0, t1, dtype=np.uint64), 0, p
+
+    def _draw(self, launch):
+        h = (self.t * np.uint64(0x9E3779B97F4A7C15) + np.uint64(launch) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFF)
+        h = (h ^ (h >> np.uint64(21))) * np.uint64(0x94D049BB133111EB) & np.uint64(0xFFFFFFFFFFFF)
+        u = (h >> np.uint64(8)).astype(np.float64) / float(1 << 40)
+        ok = u < self.p
+        pts = np.stack([self.t.astype(np.float64), np.full(len(self.t), float(launch)), u], axis=1)
+        return ok, pts
+
+    def run(self, n_launches, capacity):
+        counts, out = np.zeros(n_launches, dtype=np.int64), []
+        for k in range(n_launches):
+            ok, pts = self._draw(self.launch)
+            self.launch += 1
+            counts[k] = ok.sum()
+            out.append(pts[ok])
+        out = np.concatenate(out) if out else np.zeros((0, 3))
+        return counts, out[:capacity]
+
+    def close(self):
+        pass
+
+
+def _worker_fill(rank, world, port, n, p, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disimpy_amd import sharding
+
+    rows = sharding.fill_mesh_sharded(n, lambda t0, t1: _FakeFill(t0, t1, p), dist)
+    q.put((rank, sharding.shard_range(n, rank, world), rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,p", [(2, 5001, 0.03), (3, 4000, 0.4), (3, 2, 0.5)])
+def test_sharded_fill_reproduces_the_single_process_sequence(world, n, p):
+    """the threads of every launch split over the ranks, only per-launch counts exchanged: same rows, same order"""
+    from disimpy_amd import sharding
+
+    want = sharding.fill_mesh_sharded(n, lambda t0, t1: _FakeFill(t0, t1, p))  # one process, all threads
+    # the single sequence itself: accepted candidates launch by launch in thread order
+    seq, f = [], _FakeFill(0, n, p)
+    while sum(len(x) for x in seq) < n:
+        seq.append(f.run(1, n)[1])
+    np.testing.assert_array_equal(want, np.concatenate(seq)[:n])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fill, args=(r, world, port, n, p, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, (a, b), rows in got:
+        np.testing.assert_array_equal(rows, want[a:b])

@@ -57,7 +57,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
     ap.add_argument("--walkers", type=int, default=1_000_000)
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--tag", default="r03")
     ap.add_argument("--match", default="walk_kernel")
     ap.add_argument("--passes", default="sq,mem,fetch,write")
     ap.add_argument("--bench-args", default="")
@@ -85,7 +85,19 @@ def main():
     json.dump(raw, open(dst, "w"), indent=1)
     T = (raw.get("sq", {}).get("bench", {}).get("config") or {}).get("time_steps") or 10000
     ws = -(-args.walkers // 64) * T
-    entry = {"walkers": args.walkers, "time_steps": T, "source": os.path.relpath(dst, ROOT)}
+    import hashlib
+
+    sys.path.insert(0, ROOT)
+    from disimpy_amd import _lib  # the path only: this process never calls into the library
+
+    M = 1
+    for tok_i, tok in enumerate(args.bench_args.split()):
+        if tok == "--measurements":
+            M = int(args.bench_args.split()[tok_i + 1])
+    entry = {"walkers": args.walkers, "time_steps": T, "source": os.path.relpath(dst, ROOT), "measurements": M,
+             "bench_args": args.bench_args,
+             # the build the counters belong to: bench.py quotes them only when it runs this very library
+             "lib_sha256": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()}
     if "sq" in raw:
         c = raw["sq"]["counters"]
         entry["kernel"] = raw["sq"]["resources"].get("kernel")
