@@ -912,7 +912,8 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       HIP_TRY(hipEventCreate(&b));
       g.ev->push_back(b);
     }
-    const int grid = (grid_for(v->n, block) + 255) & ~255; /* XCD-aware group mapping in the kernel */
+    const int grid_unit = 8 << q.xcd_run_log2;
+    const int grid = (grid_for(v->n, block) + grid_unit - 1) / grid_unit * grid_unit; /* XCD-aware group mapping in the kernel */
     HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used], v->stream));
     hipError_t e = launch_mb<GEOM_MESH>(mb, q, grid, block, lds, v->stream, h->grad_src, 1);
     if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -1093,7 +1094,18 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   size_t lds = lds_fixed + (coop4 ? 0 : (size_t)tile * mb * 4 * sizeof(double));
   if (lds > (coop ? 160u : 64u) * 1024u) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
   int grid = grid_for(h->n, block);
-  if (geom == GEOM_MESH) grid = (grid + 255) & ~255; /* XCD-aware group mapping in the kernel */
+  /* runs of 8 walker groups (2048 walkers) per XCD: measured on C5b with the counting sort's 64^3 bins, 1.25e6 walkers:
+   * runs of 1 / 2 / 4 / 8 / 16 / 32 / 64 / 128 groups give 1.085 / 1.13 / 1.18 / 1.20 / 1.18 / 1.14 / 1.10 / 0.91e10
+   * (round 2 used 32 with the full Morton sort); 1e7 walkers: 1.235 ... 1.249 ... 1.225e10 */
+  p.xcd_run_log2 = 3;
+  if (const char *e = getenv("DSIM_XCD_RUN")) { /* tuning runs */
+    const int v = atoi(e);
+    if (v >= 0 && v <= 10) p.xcd_run_log2 = v;
+  }
+  if (geom == GEOM_MESH) {
+    const int grid_unit = 8 << p.xcd_run_log2;
+    grid = (grid + grid_unit - 1) / grid_unit * grid_unit; /* XCD-aware group mapping in the kernel */
+  }
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
   int resort = 0;
   if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX && !h->recording) {

@@ -124,6 +124,7 @@ struct WalkParams {
   /* with tcur: {walkers not yet at t_end, time steps they still have to take, the most any of them has left}, added up
    * by the kernel itself at the end of the launch (one atomic each per wavefront); nullptr: not asked */
   unsigned long long *progress;
+  int xcd_run_log2; /* mesh: an XCD takes runs of 1 << xcd_run_log2 consecutive walker groups (the grid is a multiple of 8 such runs) */
 };
 
 /* ---- one walker, one time step, by substrate -------------------------------- */
@@ -510,15 +511,16 @@ DSD void walk_body(const WalkParams &p_arg) {
   const double *xs = bounds, *ys = bounds + p.mesh.nx + 1, *zs = bounds + p.mesh.nx + p.mesh.ny + 2;
 
   /* Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every
-   * XCD has its own L2.  Mesh walkers are Morton-sorted: an XCD takes runs of 32 consecutive
-   * walker groups (8192 walkers, a compact region of space whose part of the index stays in that
+   * XCD has its own L2.  Mesh walkers are sorted in space: an XCD takes runs of 1 << xcd_run_log2 consecutive
+   * walker groups (default 8 groups = 2048 walkers, a compact region whose part of the index stays in that
    * XCD's L2), the runs are dealt to the XCDs in turn so that dense and sparse regions spread
    * evenly (giving every XCD one contiguous eighth was 11 % slower on the neuron).  The host
-   * rounds the grid up to a multiple of 256; groups beyond the last walker are empty. */
+   * rounds the grid up to a multiple of 8 runs; groups beyond the last walker are empty. */
   int64_t group = blockIdx.x;
   if (GEOM == GEOM_MESH) {
     const unsigned slot = blockIdx.x >> 3; /* position in the XCD's own sequence */
-    group = ((int64_t)(slot >> 5) * 8 + (blockIdx.x & 7)) * 32 + (slot & 31);
+    const int rl = p.xcd_run_log2;
+    group = (((int64_t)(slot >> rl) * 8 + (blockIdx.x & 7)) << rl) + (slot & ((1u << rl) - 1u));
   }
   const int64_t i = group * blockDim.x + threadIdx.x;
   const bool live = i < p.n;

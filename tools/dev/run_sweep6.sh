@@ -1,0 +1,19 @@
+mkdir -p gpurun_out/r03
+run() { # tag N env extra
+  DSIM_BENCH_POSITIONS_CACHE=/tmp/pos_c5b_$2.npy env $3 timeout -k 5 300 python bench.py --workload c5b --walkers $2 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check $4 > gpurun_out/r03/sw_$1.json 2> gpurun_out/r03/sw_$1.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/r03/sw_$1.json").read().strip().splitlines()[-1]); print("$1: %.4g  walk %.4g" % (d["value"], d["walk_kernel_spin_steps_per_s"]))
+except Exception as e: print("$1 FAILED", e)
+PY
+}
+run f_x5 1250000 DSIM_XCD_RUN=5 ""
+run f_x3 1250000 DSIM_XCD_RUN=3 ""
+run f_x4 1250000 DSIM_XCD_RUN=4 ""
+run f_x6 1250000 DSIM_XCD_RUN=6 ""
+run f_x7 1250000 DSIM_XCD_RUN=7 ""
+run f_x5b 1250000 DSIM_XCD_RUN=5 ""
+run f10_x5 10000000 DSIM_XCD_RUN=5 ""
+run f10_x7 10000000 DSIM_XCD_RUN=7 ""
+run f10_x3 10000000 DSIM_XCD_RUN=3 ""
