@@ -792,6 +792,8 @@ struct WalkGroup {
   int *ev_used = nullptr;
   unsigned long long *counters = nullptr; /* [2][4] on the device: see dsim_sim::counters */
   int launch_no = 0;                      /* launch k uses counter set k & 1 */
+  double *traj = nullptr;                 /* recorded mode: this group's [step][3][n] region of the handle's buffer */
+  int32_t t_pos = 0;                      /* recorded mode: the time step the group has reached */
   double clear_frac = -1;                 /* share of walkers in clear cells as of the last launch's sort (-1: unknown) */
   long long unfinished = 0, steps_left = 0, max_left = 0;
   double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
@@ -807,7 +809,13 @@ static int walker_groups(const dsim_sim *h) {
 }
 
 static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bool clear_auto, int mb, int block, size_t lds, int resort,
-                         int32_t t_begin, int32_t t_end) {
+                         int32_t t_begin, int32_t t_end, int mb_phase = 0) {
+  /* mb_phase > 0: more than two measurements - the walk kernel carries no accumulators and records the positions of a
+   * range of steps (h->traj, cut into one region per group), phase_from_traj_kernel<mb_phase> then adds the phases up on
+   * the same stream.  A launch then is a range of time steps common to the walkers of a group (no per-walker clocks: the
+   * accumulation wants one gradient tile per workgroup), but the groups still run on their own streams: one group's
+   * sort, walk and phase kernels fill what the other's leaves free. */
+  const bool recorded = mb_phase > 0;
   const int n_groups = walker_groups(h);
   if (!h->clear_count) HIP_TRY(hipMalloc(&h->clear_count, sizeof(unsigned long long)));
   /* Walker groups are index ranges of the handle's arrays.  Cut out of the caller's order every group is a random
@@ -841,6 +849,8 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       g.v.phase += g.off, g.v.phase_alt += g.off, g.v.exc += g.off, g.v.exc_alt += g.off, g.v.bin_of += g.off;
     }
     g.permuted = presorted; /* orig[] already holds the walkers' original indices */
+    g.traj = recorded ? h->traj + (size_t)h->traj_steps * 3 * g.off : nullptr;
+    g.t_pos = t_begin;
     g.unfinished = g.v.n;
     g.steps_left = (long long)g.v.n * (t_end - t_begin);
     g.max_left = t_end - t_begin;
@@ -860,6 +870,58 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
   auto issue = [&](WalkGroup &g) -> int {
     dsim_sim *v = &g.v;
     if (--g.launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
+    if (recorded) {
+      const int32_t ta = g.t_pos, tb = std::min<int32_t>(t_end, ta + std::min(resort, h->traj_steps));
+      int rc = resort_walkers(v, !g.permuted, false, 0, false, (int)(&g - grp));
+      if (rc) return rc;
+      g.permuted = true;
+      WalkParams q = p;
+      const int c = v->cur;
+      q.n = v->n;
+      q.x_in = q.x_out = v->x[c], q.y_in = q.y_out = v->y[c], q.z_in = q.z_out = v->z[c];
+      q.s0_in = q.s0_out = v->s0[c], q.s1_in = q.s1_out = v->s1[c];
+      q.phase = v->phase, q.exc = v->exc;
+      q.t_begin = ta, q.t_end = tb;
+      q.tile_steps = tb - ta; /* gradient from global memory: one "tile" per launch */
+      q.traj = g.traj;
+      q.tcur = nullptr, q.progress = nullptr, q.iter_budget = INT_MAX;
+      q.m0 = 0, q.mc = 0, q.write_state = true;
+      if (*g.ev_used + 2 > (int)g.ev->size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreate(&a));
+        g.ev->push_back(a);
+        HIP_TRY(hipEventCreate(&b));
+        g.ev->push_back(b);
+      }
+      const int grid_unit = 8 << q.xcd_run_log2;
+      const int grid = (grid_for(v->n, block) + grid_unit - 1) / grid_unit * grid_unit;
+      HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used], v->stream));
+      hipError_t e = launch_mb<GEOM_MESH>(1, q, grid, block, lds, v->stream, h->grad_src, 1);
+      if (e != hipSuccess) return fail(DSIM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+      HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used + 1], v->stream));
+      *g.ev_used += 2;
+      h->last_launches++;
+      const int tile_p = std::max(1, 16384 / (mb_phase * 32));
+      const size_t lds_p = (size_t)tile_p * mb_phase * 4 * sizeof(double);
+      const int grid_p = grid_for(v->n, 256);
+      for (int m0 = 0; m0 < h->M; m0 += mb_phase) {
+        const int mc = std::min(mb_phase, h->M - m0);
+#define DSIM_PHASE_LAUNCH_G(MBV)                                                                                                    \
+  phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, v->stream>>>(g.traj, v->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, p.gdt, v->phase, \
+                                                                 h->phase_stride)
+        switch (mb_phase) {
+          case 4: DSIM_PHASE_LAUNCH_G(4); break;
+          case 8: DSIM_PHASE_LAUNCH_G(8); break;
+          case 16: DSIM_PHASE_LAUNCH_G(16); break;
+          default: DSIM_PHASE_LAUNCH_G(32); break;
+        }
+#undef DSIM_PHASE_LAUNCH_G
+        HIP_TRY(hipGetLastError());
+      }
+      g.t_pos = tb;
+      g.inflight = true;
+      return DSIM_OK;
+    }
     /* aim at `resort` time steps per walker and launch; once nobody has much more than that left, the launch runs
      * every walker to t_end (wavefronts end when their last lane is done, as without clocks) */
     g.budget = g.max_left <= (long long)resort + resort / 4 ? INT_MAX : (int)std::ceil(g.passes_per_step * resort) + 2;
@@ -925,6 +987,12 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
   };
   /* wait for the group's launch and read how far its walkers got */
   auto collect = [&](WalkGroup &g) -> int {
+    if (recorded) {
+      HIP_TRY(hipStreamSynchronize(g.v.stream));
+      g.inflight = false;
+      g.unfinished = g.t_pos < t_end ? g.v.n : 0;
+      return DSIM_OK;
+    }
     unsigned long long pr[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(pr, g.counters + 4 * (g.launch_no & 1), sizeof(pr), hipMemcpyDeviceToHost, g.v.stream));
     HIP_TRY(hipStreamSynchronize(g.v.stream));
@@ -1168,6 +1236,11 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   /* mesh, cooperative kernel, re-sorted walkers, nothing recorded: per-walker clocks (run_own_clock) */
   if (coop4 && resort > 0 && !record && passes == 1 && h->mesh_traversal != 5)
     return run_own_clock(h, p, clear_map, clear_auto, mb, block, lds, resort, t_begin, t_end);
+  /* the same with more than two measurements: positions recorded per range of steps, phases added up from them */
+  if (coop4 && split_phase && !h->recording && resort > 0 && h->mesh_traversal != 5) {
+    if (clear_auto) p.mesh.clear_idx = nullptr;
+    return run_own_clock(h, p, clear_map, false, mb, block, lds, resort, t_begin, t_end, mb_all);
+  }
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   bool permuted = false;
   /* the time loop; any failure inside leaves through `return`, and the walker order is put back
@@ -1249,7 +1322,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
         const int mc = std::min(mb_all, h->M - m0);
 #define DSIM_PHASE_LAUNCH(MBV)                                                                                             \
   phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(h->traj, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \
-                                                                 p.gdt, h->phase)
+                                                                 p.gdt, h->phase, h->phase_stride)
         switch (mb_all) {
           case 1: DSIM_PHASE_LAUNCH(1); break;
           case 2: DSIM_PHASE_LAUNCH(2); break;

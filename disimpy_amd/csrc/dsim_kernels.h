@@ -749,13 +749,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
  * time - does the rest.  traj = [step][3][n]; the gradient tile lives in LDS as in walk_body. */
 template <int MB>
 __global__ __launch_bounds__(256) void phase_from_traj_kernel(const double *traj, int64_t n, int steps, int tile_steps, const double *g4,
-                                                              int M, int m0, int mc, int t_first, double gdt, double *phase) {
+                                                              int M, int m0, int mc, int t_first, double gdt, double *phase,
+                                                              int64_t phase_stride) {
   extern __shared__ double gt[];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   double ph[MB];
 #pragma unroll
-  for (int m = 0; m < MB; m++) ph[m] = (live && m < mc) ? phase[(int64_t)(m0 + m) * n + i] : 0.0;
+  for (int m = 0; m < MB; m++) ph[m] = (live && m < mc) ? phase[(int64_t)(m0 + m) * phase_stride + i] : 0.0;
   for (int t0 = 0; t0 < steps; t0 += tile_steps) {
     const int kt = min(tile_steps, steps - t0);
     __syncthreads();
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(256) void phase_from_traj_kernel(const double *traj
   if (live) {
 #pragma unroll
     for (int m = 0; m < MB; m++)
-      if (m < mc) phase[(int64_t)(m0 + m) * n + i] = ph[m];
+      if (m < mc) phase[(int64_t)(m0 + m) * phase_stride + i] = ph[m];
   }
 }
 

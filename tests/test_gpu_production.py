@@ -137,6 +137,35 @@ def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_ex
         _assert_identical(gpu, ref)
 
 
+@pytest.mark.parametrize("groups", [1, 2, 3])
+def test_many_measurements_on_a_mesh_through_the_group_driver(lib, oracle_exact, monkeypatch, groups):
+    """M = 5 and M = 40 on a mesh with re-sorted walkers: positions recorded per range of steps, phases added up from
+    them (phase_from_traj_kernel), one / two / three walker groups on their own streams with ragged sizes, two calls."""
+    from disimpy_amd import substrates
+
+    m = golden("cylinder_mesh_closed.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, n_sv=np.array([10, 10, 10]), perm_prob=0.2, quiet=True)
+    n, T, dt = 12289, 500, 1e-3
+    step_l = float(np.sqrt(6 * D * dt))
+    pos0 = np.random.RandomState(6).random_sample((n, 3)) * sub.voxel_size
+    ma = _mesh_arrays(sub)
+    monkeypatch.setenv("DSIM_GROUPS", str(groups))
+    for M in (5, 40):
+        g = _random_gradient(M, T)
+        ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 13, perm_prob=0.2)
+        with lib.Sim(n, g, dt, step_l) as sim:
+            sim.set_tuning(resort_steps=96)
+            sim.rng_init_device(13)
+            sim.set_positions(pos0)
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+            sim.run_mesh(1000, 1e-13, 0.2, 0, 230)
+            sim.run_mesh(1000, 1e-13, 0.2, 230, T)
+            assert sim.last_walk_busy_ms()[1] == groups
+            c, s, _ = sim.signal()
+            gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s)
+        _assert_identical(gpu, ref)
+
+
 def test_c4_packed_cylinders_bit_identical(lib, oracle_exact):
     """BASELINE config C4 (bench.packed_cylinders: 4096 triangles, periodic, uniform positions,
     50^3 index), 4096 walkers x 500 steps of the C4 waveform's step length, re-sorted every 128 steps."""
