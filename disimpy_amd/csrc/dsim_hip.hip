@@ -1201,6 +1201,9 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     }
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
+    /* the counting sort leaves its histograms zeroed for the next time; a run that failed half-way may not have */
+    for (int g = 0; g < DSIM_MAX_GROUPS; g++)
+      HIP_TRY(hipMemsetAsync(h->sort_hist[g], 0, (((size_t)1 << h->sort_bits) + 1) * sizeof(uint32_t), h->stream));
   }
   h->rec_t0 = h->rec_t1 = 0;
   if (record) {
