@@ -345,7 +345,7 @@ def kernel_name(sub, M, args):
     mb = 1 << max(0, (min(M, 32) - 1).bit_length())
     if sub.type != "mesh" or args.mesh_traversal == 1:
         return "walk_kernel<%s,%d>" % (sub.type, mb)
-    return "walk_kernel_coop4<%d>" % mb if mb <= 2 else "walk_kernel_coop4_traj + phase_from_traj_kernel<%d>" % mb
+    return "walk_kernel_coop4<%d>" % mb if mb <= 4 else "walk_kernel_coop4_traj + phase_from_traj_kernel<%d>" % mb
 
 
 def profile_entry(workload):
@@ -581,7 +581,7 @@ def main(argv=None):
         "note": "register-resident fused kernel: bound by vector-ALU time and dependent index look-ups, not by "
                 "HBM.  Deviations from the north star's sketch, measured and kept: the mesh kernel reads triangle "
                 "records through L1/L2 (7 MB index, Morton-sorted walkers) instead of staging lists in LDS, and "
-                "with M <= 2 it reads the gradient samples from global memory (32 B per step out of L1) instead "
+                "with M <= 4 it reads the gradient samples from global memory (32 B per measurement and step out of L1) instead "
                 "of an LDS tile; LDS holds the log/cos tables, the subvoxel boundaries and the wave work queues.",
     }
     out = {

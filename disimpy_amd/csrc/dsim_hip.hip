@@ -601,8 +601,9 @@ extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_ve
 /* The scalar-load (SMEM) gradient path was measured at half the speed of the LDS tiles
  * (C2: 3.1e10 vs 6.0e10 spin-steps/s); its kernels are only instantiated when the library is
  * built with -DDSIM_SMEM_GRADIENT (halves the build time otherwise). */
-/* cooperative mesh kernels with at most this many phase accumulators run at 4 waves/SIMD */
-#define COOP4_MAX_MB 2
+/* cooperative mesh kernels with at most this many phase accumulators run at 4 waves/SIMD (4 accumulators: 125 VGPRs,
+ * nothing spilled; 8 would not fit 128) */
+#define COOP4_MAX_MB 4
 
 template <int GEOM, int MB>
 static hipError_t launch_one(const WalkParams &p, int grid, int block, size_t lds, hipStream_t s, int gsrc, int coop) {

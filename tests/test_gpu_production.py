@@ -111,7 +111,7 @@ def test_neuron_shard_large_enough_for_two_groups_by_default(lib, oracle_exact, 
 
 def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_exact, monkeypatch):
     """Two independently sorted halves (DSIM_GROUPS=2) of an odd number of walkers - 9001 = 4608 + 4393 - in the
-    closed cylinder mesh with permeable walls (crossings draw an extra uniform), with one and with two measurements
+    closed cylinder mesh with permeable walls (crossings draw an extra uniform), with one to four measurements
     (the rows of the phase matrix of a half keep the handle's row stride)."""
     from disimpy_amd import substrates
 
@@ -122,7 +122,7 @@ def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_ex
     pos0 = np.random.RandomState(5).random_sample((n, 3)) * sub.voxel_size
     ma = _mesh_arrays(sub)
     monkeypatch.setenv("DSIM_GROUPS", "2")
-    for M in (1, 2):
+    for M in (1, 2, 3, 4):  # up to four phase accumulators ride in the cooperative kernel's registers
         g = _random_gradient(M, T)
         ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 11, perm_prob=0.35)
         with lib.Sim(n, g, dt, step_l) as sim:
