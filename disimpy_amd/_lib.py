@@ -19,7 +19,7 @@ SYMBOLS = (
     "dsim_get_signal", "dsim_get_positions", "dsim_get_phases", "dsim_get_iter_exc", "dsim_get_rng_states",
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
-    "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close",
+    "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close", "dsim_mesh_fine_grid",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -81,6 +81,8 @@ def load():
                                         _i64p]
     lib.dsim_mesh_clearance_map.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, C.c_double,
                                             _i32p, C.POINTER(C.c_uint32), _i64p, _i32p]
+    lib.dsim_mesh_fine_grid.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, C.c_double,
+                                        _i32p, _i64p, _i64p, _i32p, C.POINTER(C.c_uint32), _i32p, _i32p, C.POINTER(C.c_float)]
     lib.dsim_triangle_box_overlap.argtypes = [_f64p, _f64p]
     lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
     lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
@@ -163,6 +165,27 @@ def mesh_clearance_map(vertices, faces, xs, ys, zs, n_sv, step_l):
                                       step_l, idx.ctypes.data_as(_i32p), bits.ctypes.data_as(C.POINTER(C.c_uint32)),
                                       C.byref(n_words), C.byref(lf)))
     return idx, bits, 1 << lf.value
+
+
+def mesh_fine_grid(vertices, faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, step_l):
+    """The fine grid of dsim_set_mesh (host only): dict(lk, sv_base or None, cell_start, tri, pos, box (n, 6))."""
+    lib = load()
+    v, f = _c(vertices, np.float64), _c(faces, np.int64)
+    xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+    nsv = _c(n_sv, np.int64)
+    svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
+    lk, nc, nr = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+    args = (p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri), len(tri), float(step_l))
+    check(lib.dsim_mesh_fine_grid(*args, C.byref(lk), C.byref(nc), C.byref(nr), None, None, None, None, None))
+    sv_base = np.full(int(np.prod(nsv)), -1, dtype=np.int32)
+    cell_start = np.zeros(nc.value + 1, dtype=np.uint32)
+    rt, rp = np.zeros(max(nr.value, 1), dtype=np.int32), np.zeros(max(nr.value, 1), dtype=np.int32)
+    box = np.zeros((max(nr.value, 1), 6), dtype=np.float32)
+    check(lib.dsim_mesh_fine_grid(*args, C.byref(lk), C.byref(nc), C.byref(nr), sv_base.ctypes.data_as(_i32p),
+                                  cell_start.ctypes.data_as(C.POINTER(C.c_uint32)), rt.ctypes.data_as(_i32p), rp.ctypes.data_as(_i32p),
+                                  box.ctypes.data_as(C.POINTER(C.c_float))))
+    return dict(lk=lk.value, sv_base=sv_base if lk.value > 0 else None, cell_start=cell_start, tri=rt[: nr.value], pos=rp[: nr.value],
+                box=box[: nr.value])
 
 
 def triangle_box_overlap(triangle, box):

@@ -587,6 +587,38 @@ extern "C" int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertice
   return DSIM_OK;
 }
 
+/* host only: the fine grid dsim_set_mesh builds for this mesh and step length */
+extern "C" int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
+                                   const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                                   const int64_t *triangle_indices, int64_t n_refs, double step_l, int32_t *log2_cells, int64_t *n_cells,
+                                   int64_t *n_records, int32_t *sv_base, uint32_t *cell_start, int32_t *rec_triangle, int32_t *rec_position,
+                                   float *rec_box) {
+  if (!log2_cells || !n_cells || !n_records) return fail(DSIM_ERR_INVALID, "dsim_mesh_fine_grid: null argument");
+  HostFineGrid fg;
+  DevMesh none;
+  int rc = upload_mesh(none, nullptr, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, step_l, &fg);
+  if (rc) return rc;
+  const int64_t cells = (int64_t)fg.cell_start.size() - 1, recs = (int64_t)fg.cell_start.back();
+  if (cell_start) { /* second call: the caller's buffers hold the sizes of the first */
+    if (*n_cells < cells || *n_records < recs) return fail(DSIM_ERR_INVALID, "dsim_mesh_fine_grid: buffers too small");
+    if (sv_base && fg.lk > 0) memcpy(sv_base, fg.sv_base.data(), fg.sv_base.size() * sizeof(int32_t));
+    memcpy(cell_start, fg.cell_start.data(), fg.cell_start.size() * sizeof(uint32_t));
+    for (int64_t r = 0; r < recs; r++) {
+      const float4 q0 = fg.mrec[3 * r], q1 = fg.mrec[3 * r + 1], q2 = fg.mrec[3 * r + 2];
+      if (rec_triangle) memcpy(&rec_triangle[r], &q2.z, 4);
+      if (rec_position) memcpy(&rec_position[r], &q2.w, 4);
+      if (rec_box) {
+        const float b[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}; /* min x y z, max x y z */
+        memcpy(rec_box + 6 * r, b, sizeof(b));
+      }
+    }
+  }
+  *log2_cells = fg.lk;
+  *n_cells = cells;
+  *n_records = recs;
+  return DSIM_OK;
+}
+
 extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
                              const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                              const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs) {

@@ -332,9 +332,18 @@ static bool clipped_triangle_box(const double *const tv[3], const double org[3],
   return true;
 }
 
+/* the fine grid as built on the host (dsim_mesh_fine_grid hands it out so that its completeness can be tested without a GPU) */
+struct HostFineGrid {
+  int lk = 0;
+  std::vector<int32_t> sv_base;
+  std::vector<uint32_t> cell_start;
+  std::vector<float4> mrec;
+};
+
 static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
                        int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
-                       const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l) {
+                       const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l,
+                       HostFineGrid *host_only = nullptr) {
   if (!vertices || !faces || !xs || !ys || !zs || !n_sv || !subvoxel_indices || (!triangle_indices && n_refs))
     return fail(DSIM_ERR_INVALID, "mesh: null argument");
   if (n_faces <= 0 || n_vertices <= 0 || n_faces > INT32_MAX || n_refs > INT32_MAX || n_refs < 0)
@@ -343,7 +352,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (n_sv[k] < 1 || n_sv[k] > 4096) return fail(DSIM_ERR_INVALID, "mesh: n_sv[%d] = %lld out of range", k, (long long)n_sv[k]);
   const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
   if (n_sub > INT32_MAX) return fail(DSIM_ERR_INVALID, "mesh: too many subvoxels");
-  free_mesh(dm);
+  if (!host_only) free_mesh(dm);
   /* pre-gathered triangle records {A, B - A, C - A} (simulations.py:259-262 does these subtractions per candidate) */
   std::vector<double> rec((size_t)n_faces * DS_TRI_STRIDE);
   for (int64_t f = 0; f < n_faces; f++) {
@@ -523,6 +532,13 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (mrec.size() / 3 >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
     cell_start.push_back((uint32_t)(mrec.size() / 3)); /* end of the last cell */
     if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
+  }
+  if (host_only) { /* no device involved */
+    host_only->lk = lk;
+    host_only->sv_base.swap(sv_base);
+    host_only->cell_start.swap(cell_start);
+    host_only->mrec.swap(mrec);
+    return DSIM_OK;
   }
   std::vector<double> bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
