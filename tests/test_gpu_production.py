@@ -352,3 +352,43 @@ def test_trajectories_file_native_writer(lib, oracle_exact, tmp_path):
     assert open(path, "rb").read() == open(want, "rb").read()
     print("trajectories: native %.3f s, python %.3f s" % (t_native, t_python))
     assert t_native * 10 < t_python
+
+
+@pytest.mark.parametrize("grid", ["uneven", "offset"])
+def test_a_grid_that_is_not_the_references_linspace_takes_the_checked_traversal(lib, oracle_exact, grid):
+    """the cooperative traversal's float32 shortcut and arithmetic cell coordinates assume
+    xs = linspace(0, L, n + 1).  Boundaries handed in through the C ABI that are not (one boundary moved by 3 % of a
+    subvoxel; all boundaries offset from 0) must not diverge silently: upload_mesh detects them and the per-lane traversal,
+    which checks every guess against the boundary values, runs instead - M = 1, 4, 40 and a recorded run, default tuning,
+    against the oracle on the same irregular grid."""
+    from disimpy_amd import substrates
+
+    m = golden("cylinder_mesh_closed.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.array([1e-6, 1e-6, 0.0]), n_sv=np.array([6, 6, 12]), quiet=True)
+    xs, ys, zs = sub.xs.copy(), sub.ys.copy(), sub.zs.copy()
+    if grid == "uneven":
+        xs[2] += 0.03 * (xs[1] - xs[0])
+        zs[5] -= 0.02 * (zs[1] - zs[0])
+    else:
+        ys = ys + 0.25 * (ys[1] - ys[0])  # xs[0] != 0: the reference's own periodic arithmetic, whatever it does with it
+    tri, svi = lib.mesh_subdivide(sub.vertices, sub.faces, xs, ys, zs, sub.n_sv)
+    ma = dict(vertices=sub.vertices, faces=sub.faces, xs=xs, ys=ys, zs=zs, n_sv=sub.n_sv,
+              subvoxel_indices=np.ascontiguousarray(svi, dtype=np.int64), triangle_indices=np.ascontiguousarray(tri, dtype=np.int64))
+    n, T, dt = 5000, 60, 5e-4
+    step_l = float(np.sqrt(6 * D * dt))
+    pos0 = np.random.RandomState(8).random_sample((n, 3)) * sub.voxel_size
+    for M in (1, 4, 40):
+        g = _random_gradient(M, T)
+        ref = _oracle_mesh(oracle_exact, ma, n, g, dt, step_l, pos0, 21, want_traj=(M == 4))
+        with lib.Sim(n, g, dt, step_l) as sim:
+            sim.rng_init_device(21)
+            sim.set_positions(pos0)
+            sim.set_mesh(ma["vertices"], ma["faces"], xs, ys, zs, ma["n_sv"], ma["subvoxel_indices"], ma["triangle_indices"])
+            if M == 4:
+                sim.set_recording(True)
+            sim.run_mesh(1000, 1e-13, 0.0, 0, T)
+            if M == 4:
+                npt.assert_array_equal(sim.recorded(0, T), ref["traj"])
+            c, s_, _ = sim.signal()
+            gpu = dict(pos=sim.positions(), phases=sim.phases(), exc=sim.iter_exc(), states=sim.rng_states(), cos=c, sin=s_)
+        _assert_identical(gpu, ref)
