@@ -16,8 +16,7 @@
  *             cut into 4-record items (slots from a wave prefix sum);
  *   stage 2   any lane per item: 4 records tested (float32 AABB + plane)
  *             against the OWNER's cull box -> survivor pool, slots from wave
- *             ballots (a survivor that names a triangle its owner already has
- *             in the pool is dropped);
+ *             ballots;
  *   stage 3   any lane per survivor: fp64 Moller-Trumbore test with the OWNER's
  *             ray, minimum per owner by 64-bit LDS atomics on the bit pattern
  *             of d; a second atomic pass names the winner's triangle and
@@ -58,9 +57,6 @@
 #define COOP_RUNQ_CAP 320 /* slots 0..63: the first run of owner 0..63; the other runs behind */
 #define COOP_MAX_RUNS 64  /* per owner and pass */
 #define COOP_NO_SHIFT 0x20820u /* (tag >> 6) & 0x3ffff when all three image numbers are 0 (stored + 32, 6 bits each) */
-#ifndef COOP_DEDUPE
-#define COOP_DEDUPE 1
-#endif
 
 /* Per-wavefront scratch in LDS (7.9 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
@@ -75,9 +71,6 @@ struct CoopWave {
   uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 30, owner | shifts << 6} (1c -> 2)  2.5 KB */
   unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
   unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6                                                   1.0 KB */
-#if COOP_DEDUPE
-  unsigned filt[64][2];            /* the last unshifted triangles this owner put into the pool (2-way, hashed) 0.5 KB */
-#endif
   unsigned char overflow[64];      /* some work of this owner did not fit a queue: redo serially                     */
   unsigned char tie[64];           /* two different triangles share this owner's smallest d: the reference's order decides */
   int pad[4];
@@ -384,9 +377,6 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   if (__ballot(act) == 0ULL) return finished;
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
   W->best_tri[lane] = 0xffffffffu;
-#if COOP_DEDUPE
-  W->filt[lane][0] = W->filt[lane][1] = 0xffffffffu;
-#endif
   W->overflow[lane] = 0;
   W->tie[lane] = 0;
   T_MARK(W, lane, 1);
@@ -569,23 +559,6 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           for (int u = 0; u < 4; u++) alive |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
           alive &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
           if (ABLATE(3) || ABLATE(4)) alive = 0;
-#if COOP_DEDUPE
-          /* A triangle reaches the pool through every cell it shares with the segment's box (17 % of the survivors on
-           * the neuron were repeats): the owner's last survivors are remembered in a 2-way hashed table and a repeat
-           * is dropped - the fp64 test of the same triangle and ray returns the same d, and the first copy is already
-           * in the pool or has been tested.  Only for the unshifted image (the table holds the triangle alone) and
-           * only for a lane's first survivor (one LDS atomic per lane and trip; a lane rarely has two); of two lanes
-           * that offer the same triangle at once exactly one sees the other's entry. */
-          if (alive && !shifted) {
-            const unsigned u0 = (unsigned)__builtin_ctz(alive);
-            const float tf = u0 == 0 ? q2[0].z : (u0 == 1 ? q2[1].z : (u0 == 2 ? q2[2].z : q2[3].z));
-            const unsigned t = (unsigned)__float_as_int(tf);
-            if (atomicExch(&W->filt[owner][(t ^ (t >> 1)) & 1u], t) == t) {
-              alive &= alive - 1u;
-              STAT_LANE(7);
-            }
-          }
-#endif
           alive_w = alive;
 #pragma unroll
           for (int u = 0; u < 4; u++) tz[u] = q2[u].z;
