@@ -527,42 +527,39 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const bool valid = idx < n_items;
         uint2 it = make_uint2(0u, 0u);
         if (valid) it = W->items[idx];
+        /* the records first: their addresses only need the item, so the 12 loads are in flight while the owner's
+         * segment comes through the shuffles (a lane without an item reads record 0) */
+        const int first_rec = valid ? (int)(it.x & 0x3fffffffu) : 0, cnt = valid ? (int)(it.x >> 30) + 1 : 1;
+        float4 q0[4], q1[4], q2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
+          q0[u] = ms.mrec[3 * j];
+          q1[u] = ms.mrec[3 * j + 1];
+          q2[u] = ms.mrec[3 * j + 2];
+        }
         const int owner = (int)(it.y & 63u);
         CullBox cb;
         cb.mx = __shfl(cb0.mx, owner, 64), cb.my = __shfl(cb0.my, owner, 64), cb.mz = __shfl(cb0.mz, owner, 64);
         cb.hx = __shfl(cb0.hx, owner, 64), cb.hy = __shfl(cb0.hy, owner, 64), cb.hz = __shfl(cb0.hz, owner, 64);
         cb.tau = __shfl(cb0.tau, owner, 64);
         box_from_segment(cb);
-        unsigned alive_w = 0; /* this lane's survivors of the trip (0 for a lane without an item) */
-        float tz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (valid) {
           STAT_LANE(4);
           STAT_WAVE(4);
-          const int first_rec = (int)(it.x & 0x3fffffffu), cnt = (int)(it.x >> 30) + 1;
-          const bool shifted = (it.y >> 6) != COOP_NO_SHIFT;
-          if (shifted) { /* periodic image: move the box into its frame */
-            const int snx = (int)((it.y >> 6) & 63u) - 32, sny = (int)((it.y >> 12) & 63u) - 32, snz = (int)((it.y >> 18) & 63u) - 32;
-            cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
-          }
-          float4 q0[4], q1[4], q2[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
-            q0[u] = ms.mrec[3 * j];
-            q1[u] = ms.mrec[3 * j + 1];
-            q2[u] = ms.mrec[3 * j + 2];
-          }
-          /* the four tests without a branch between them (with 64 lanes x 4 records somebody always passes the
-           * box, so a branch only costs mask juggling) */
-          unsigned alive = 0;
-#pragma unroll
-          for (int u = 0; u < 4; u++) alive |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
-          alive &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
-          if (ABLATE(3) || ABLATE(4)) alive = 0;
-          alive_w = alive;
-#pragma unroll
-          for (int u = 0; u < 4; u++) tz[u] = q2[u].z;
         }
+        if (valid && (it.y >> 6) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
+          const int snx = (int)((it.y >> 6) & 63u) - 32, sny = (int)((it.y >> 12) & 63u) - 32, snz = (int)((it.y >> 18) & 63u) - 32;
+          cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+        }
+        /* the four tests without a branch between or around them (with 64 lanes x 4 records somebody always passes
+         * the box, so a branch only costs mask juggling); a lane without an item tests record 0 for nothing */
+        unsigned alive_w = 0; /* this lane's survivors of the trip */
+#pragma unroll
+        for (int u = 0; u < 4; u++) alive_w |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
+        alive_w &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
+        if (!valid || ABLATE(3) || ABLATE(4)) alive_w = 0;
+        const float tz[4] = {q2[0].z, q2[1].z, q2[2].z, q2[3].z};
         { /* the survivors' slots from four ballots (survivors in lower lanes first): the pool's fill level stays in a
            * scalar register, there is no LDS atomic to wait for and no counter to read back before the flush check
            * (round 2 / early round 3: one LDS atomic per lane and an LDS read per trip; C5b +1.4 %, C4 +1.7 %) */
