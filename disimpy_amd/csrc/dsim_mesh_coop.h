@@ -300,6 +300,10 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   const bool valid = lane < count;
   unsigned tri = 0u, tag = 0u;
   if (valid) tri = W->surv_tri[idx], tag = W->surv_tag[idx];
+  /* the triangle first: its address only needs the survivor, so the nine loads are in flight while the owner's ray
+   * comes through the shuffles (a lane without a survivor reads triangle 0) */
+  const double *rec = ms.tri + (int64_t)(int)tri * DS_TRI_STRIDE;
+  const V3 tA = load_v3(rec), tE1 = load_v3(rec + 3), tE2 = load_v3(rec + 6);
   const int owner = (int)(tag & 63u);
   V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
   const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
@@ -311,8 +315,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
       const int snx = (int)((tag >> 6) & 63u) - 32, sny = (int)((tag >> 12) & 63u) - 32, snz = (int)((tag >> 18) & 63u) - 32;
       tr0.x -= (double)snx * Lx, tr0.y -= (double)sny * Ly, tr0.z -= (double)snz * Lz;
     }
-    const double *rec = ms.tri + (int64_t)(int)tri * DS_TRI_STRIDE;
-    d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, st);
+    d = ray_triangle_intersection_check(tA, tE1, tE2, tr0, st);
     if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
   }
   wave_sync();
