@@ -27,7 +27,7 @@ def _find(kernels, prefix):
 
 
 def test_cooperative_mesh_kernels_do_not_spill(kernels):
-    for prefix in ("walk_kernel_coop4<1, 1>", "walk_kernel_coop4<2, 1>", "walk_kernel_coop4_traj"):
+    for prefix in ("walk_kernel_coop4<1, 1>", "walk_kernel_coop4<2, 1>", "walk_kernel_coop4<4, 1>", "walk_kernel_coop4_traj"):
         for k in _find(kernels, prefix):
             assert k.get("private_segment_fixed_size", 0) == 0, (prefix, k)
             assert k.get("vgpr_spill_count", 0) == 0, (prefix, k)
