@@ -18,13 +18,16 @@ successive steps continue the same walk.
 fresh rank processes itself (before anything touches the GPU), forwards rank 0's JSON line and
 exits non-zero if any rank fails.  Under `python -m torch.distributed.run` it is a rank.
 
-Prints ONE JSON line (rank 0).  The walk kernel keeps all walker state in registers, so HBM is
-not what bounds it; `roofline` therefore reports the bound that holds - vector-ALU issue:
-`achieved` = VALU wave-instructions per second (instructions per wavefront-step from the
-rocprofv3 SQ_INSTS_VALU count of the same kernel in profiles/, times the wavefront-steps per
-second measured in THIS run with HIP events around the kernel on the library's stream) over
-`peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  The algorithmic-HBM figure
-of SURVEY.md 8d is kept in `roofline.algorithmic_hbm` with its caveat.
+Prints ONE JSON line (rank 0).  `roofline` is the contract's object for the dominant kernel (the
+cooperative mesh walk kernel): bound "hbm", `achieved` = ALGORITHMIC bytes per launch (SURVEY.md 8d:
+80 + 16 M bytes per spin-step x the spin-steps of a launch) over the kernel's average launch duration,
+measured in THIS run with HIP events on the library's streams; `traffic` = the HBM bytes per launch from
+the PMC counters in profiles/kernel_counters.json.  The kernel keeps all walker state in registers, so
+HBM is not what bounds it (frac ~ 0.15): the bound that holds - vector-ALU issue - is reported next to it
+in `roofline.valu` (VALU wave-instructions per wavefront-step from the rocprofv3 SQ_INSTS_VALU count of the
+same kernel, times the wavefront-steps per second of this run, over 1024 SIMDs x 2.4 GHz / 4 cycles), but
+only when the counters were collected from the library that is running (`counters_match_lib`: sha256 of
+libdsim_hip.so) on the same workload (`counters_match_config`).
 """
 import argparse
 import json

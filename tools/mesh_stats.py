@@ -13,7 +13,7 @@ from bench import make_workload  # noqa: E402
 from disimpy_amd import _lib, simulations  # noqa: E402
 
 NAMES = ["reflect-loop iterations", "subvoxels in range", "runs of fine cells queued", "non-empty runs",
-         "record batches (4)", "run tasks (incl. empty)", "AABB pass -> fp64 test", "repeated survivors dropped (same owner, same triangle)",
+         "record batches (4)", "run tasks (incl. empty)", "AABB pass -> fp64 test", "- (round 2: repeated survivors dropped; no longer filtered)",
          "serial: subvoxels scanned by the owner", "serial: iterations redone (queues full / tie)", "-"]
 
 
