@@ -746,7 +746,7 @@ static int resort_walkers(dsim_sim *h, bool first, bool clocks = false, int32_t 
   const MeshDev no_map = {};
   sort_count_kernel<<<g, 256, 0, h->stream>>>(sp, clear_map != nullptr ? *clear_map : no_map);
   HIP_TRY(hipGetLastError());
-  sort_scan_kernel<<<1, 256, 0, h->stream>>>(h->sort_hist[grp], h->sort_offs[grp], (1 << h->sort_bits) + 1, zero4);
+  sort_scan_kernel<<<1, SORT_SCAN_THREADS, 0, h->stream>>>(h->sort_hist[grp], h->sort_offs[grp], (1 << h->sort_bits) + 1, zero4);
   HIP_TRY(hipGetLastError());
   ScatterParams q = {};
   q.n = n, q.phase_stride = h->phase_stride, q.M = h->M;
