@@ -52,6 +52,16 @@
 #ifndef DSIM_MESH_COOP_H
 #define DSIM_MESH_COOP_H
 
+/* Wave priorities (s_setprio): the SIMD's arbiter prefers the wavefront with the higher priority when several are
+ * ready to issue.  A wavefront runs the stages that look things up (1c: sv_base -> cell_start, 2: records, 3: triangles -
+ * chains of dependent loads whose latency is what the other wavefronts have to cover) at priority 1 and everything that is
+ * pure arithmetic - the random step and the loop head in walk_body, the fp64 Moller-Trumbore tests, stage 4 - at
+ * priority 0: a wavefront about to issue loads gets there first, the arithmetic of the others fills the gaps.  Measured
+ * on the same box (profiles/history/r03_ab_a18_a21_wave_priorities.txt): C5b +1.8 %, C4 +2.4 %; the stage-2
+ * arithmetic at low priority as well, or only the look-ups of 1c at high priority, lose most of it again. */
+#define COOP_PRIO_LOOKUPS() __builtin_amdgcn_s_setprio(1)
+#define COOP_PRIO_ARITHMETIC() __builtin_amdgcn_s_setprio(0)
+
 #define COOP_ITEM_CAP 320
 #define COOP_SURV_CAP 128
 #define COOP_RUNQ_CAP 320 /* slots 0..63: the first run of owner 0..63; the other runs behind */
@@ -308,6 +318,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
   const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
   double d = 0;
+  COOP_PRIO_ARITHMETIC(); /* the loads and shuffles are issued: the test itself is arithmetic */
   if (valid) { /* pass A: distances, atomic minimum of d */
     STAT_LANE(6);
     STAT_WAVE(6);
@@ -318,6 +329,7 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
     d = ray_triangle_intersection_check(tA, tE1, tE2, tr0, st);
     if (d > 0) atomicMin(&W->best_d[owner], (unsigned long long)__double_as_longlong(d));
   }
+  COOP_PRIO_LOOKUPS();
   wave_sync();
   T_MARK(W, lane, 5);
   { /* a smaller minimum than at the last flush: what was known about the old one is void */
@@ -378,6 +390,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     act = false;
   }
   if (__ballot(act) == 0ULL) return finished;
+  COOP_PRIO_LOOKUPS();
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
   W->best_tri[lane] = 0xffffffffu;
   W->overflow[lane] = 0;
@@ -596,6 +609,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     if (n_surv > 0) flush_survivors(ms, r0, step, W, lane, seen_d, 0, n_surv);
   }
   /* ---- stage 4: resolve (simulations.py:986-997) */
+  COOP_PRIO_ARITHMETIC();
   if (act) {
     const WalkParams &p = fresh_params<KA>(p_arg);
     const MeshDev &ms = p.mesh;
