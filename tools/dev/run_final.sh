@@ -17,9 +17,11 @@ timeout -k 5 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace1250k -
 python tools/timeline.py $O/trace1250k > $O/two_stream_timeline_1250k.txt 2>&1
 rm -rf $O/trace1250k
 timeout -k 10 400 python bench.py --no-cpu-baseline --no-secondary --no-signal-check > $O/bench_after_counters.json 2> $O/bench_after_counters.err
+timeout -k 10 600 python bench.py --gpus 2 --backend gloo --walkers 2000000 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_gloo_2ranks_1gpu_line.json 2> $O/bench_gloo_2ranks.err
+timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command_line.json 2> $O/bench_driver_command.err
 ls -la $O; tail -3 $O/pytest_gpu.txt; cat $O/smoke.txt | tail -2; python - <<PY
 import json
-for f in ("bench_default_line","bench_after_counters"):
+for f in ("bench_default_line","bench_after_counters","bench_gloo_2ranks_1gpu_line","bench_driver_command_line"):
     try:
         d=json.loads(open("$O/%s.json"%f).read().strip().splitlines()[-1]); r=d["roofline"]
         print(f, d["value"], r["frac"], r["counters_match_lib"], r["valu"]["valu_busy_measured"], r["traffic"])
