@@ -69,9 +69,11 @@ def _ptr(a, typ):
 
 class Oracle:
     def __init__(self, exact=False):
-        build()
         name = "libdsim_oracle_exact.so" if exact else "libdsim_oracle.so"
-        self.lib = lib = C.CDLL(os.path.join(_HERE, name))
+        other = os.environ.get("DSIM_ORACLE_DIR")  # tools/asan_cpu.sh: a sanitizer build of the same source elsewhere
+        if not other:
+            build()
+        self.lib = lib = C.CDLL(os.path.join(other or _HERE, name))
         self.exact = exact
         assert bool(lib.dso_shared_math()) == exact
         assert lib.dso_sizeof_geom() == C.sizeof(Geom)
