@@ -394,34 +394,42 @@ def test_a_grid_that_is_not_the_references_linspace_takes_the_checked_traversal(
         _assert_identical(gpu, ref)
 
 
-def test_full_size_c5b_sample_equals_the_oracle_and_the_partition_does_not_matter(lib, oracle_exact):
-    """BASELINE size: the 1e7 walkers of the default bench workload (C5b, walkers inside the refined neuron) for the
-    first 300 steps of its waveform, in two calls.  (i) 514 walkers drawn from all over the shard are bit-identical -
-    position, phase, RNG state, iter_exc - to the oracle run on them alone from the same initial position and RNG
-    state (walkers are independent, so a sample pins the full-size run: both walker groups, the spatial pre-sort,
-    the re-sorts, per-walker clocks and the restore of the order).  (ii) The same walkers cut into two ragged shards
-    with `first_walker` offsets give the same bytes as the one shard."""
+@pytest.mark.parametrize("workload,n,t_mid,t_end", [("c5b", 10_000_000, 130, 300), ("c4", 10_000_000, 130, 300),
+                                                     ("c3", 1_000_000, 130, 300), ("c2", 1_000_000, 400, 1000)])
+def test_full_size_sample_equals_the_oracle_and_the_partition_does_not_matter(lib, oracle_exact, workload, n, t_mid, t_end):
+    """BASELINE sizes (configs C5b, C4, C3, C2): all the walkers of the bench workload for the first steps of its
+    waveform (C2: all of it), in two calls.  (i) 514 walkers drawn from all over the shard are bit-identical -
+    position, phases, RNG state, iter_exc - to the oracle run on them alone from the same initial position and RNG
+    state (walkers are independent, so a sample pins the full-size run: mesh - both walker groups, the spatial
+    pre-sort, the re-sorts, per-walker clocks and the restore of the order; C2 - the 32-accumulator kernel).  (ii) The
+    same walkers cut into two ragged shards with `first_walker` offsets give the same bytes as the one shard."""
     import hashlib
 
     from disimpy_amd import simulations
     from oracle.oracle import STATE_DTYPE
 
-    n, t_mid, t_end = 10_000_000, 130, 300
-    w = bench.make_workload("c5b", n)
+    w = bench.make_workload(workload, n)
     sub, g, dt = w["substrate"], w["gradient"], w["dt"]
     step_l = float(np.sqrt(6 * D * dt))
-    pos0 = np.ascontiguousarray(simulations._fill_mesh(n, sub, True, 123))
-    ma = _mesh_arrays(sub)
+    pos0, _ = simulations._initial_positions(n, sub, 123, True, 0)
+    pos0 = np.zeros((n, 3)) if pos0 is None else np.ascontiguousarray(pos0)
 
     def run(a, b):
         with lib.Sim(b - a, g, dt, step_l, first_walker=a) as sim:
             sim.rng_init_device(123)
             st0 = sim.rng_states()
             sim.set_positions(pos0[a:b])
-            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
-            sim.run_mesh(1000, 1e-13, 0.0, 0, t_mid)
-            sim.run_mesh(1000, 1e-13, 0.0, t_mid, t_end)
-            assert sim.last_walk_busy_ms()[1] == 2  # two walker groups
+            if sub.type == "mesh":
+                sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+            for t0, t1 in ((0, t_mid), (t_mid, t_end)):
+                if sub.type == "mesh":
+                    sim.run_mesh(1000, 1e-13, 0.0, t0, t1)
+                elif sub.type == "sphere":
+                    sim.run_sphere(sub.radius, 1000, 1e-13, t0, t1)
+                else:
+                    sim.run_free(t0, t1)
+            if sub.type == "mesh":
+                assert sim.last_walk_busy_ms()[1] == 2  # two walker groups
             return st0, sim.positions(), sim.phases(), sim.rng_states(), sim.iter_exc()
 
     st0, pos, ph, st, exc = run(0, n)
@@ -430,7 +438,7 @@ def test_full_size_c5b_sample_equals_the_oracle_and_the_partition_does_not_matte
     o_st = np.zeros(len(idx), dtype=STATE_DTYPE)
     o_st["s0"], o_st["s1"] = st0[idx, 0], st0[idx, 1]
     o_pos = np.ascontiguousarray(pos0[idx])
-    geom = oracle_exact.geom(MESH, mesh=ma, max_iter=1000, epsilon=1e-13, perm_prob=0.0)
+    geom = bench.oracle_geometry(oracle_exact, sub)
     o_ph, o_exc, _ = oracle_exact.run(geom, g, dt, step_l, o_pos, o_st, t_begin=0, t_end=t_end, n_threads=THREADS)
     npt.assert_array_equal(pos[idx], o_pos)
     npt.assert_array_equal(ph[:, idx], o_ph)
@@ -443,10 +451,10 @@ def test_full_size_c5b_sample_equals_the_oracle_and_the_partition_does_not_matte
             h.update(np.ascontiguousarray(p).tobytes())
         return h.hexdigest()
 
-    whole = [digest([x]) for x in (pos, st, np.asarray(exc, dtype=np.uint8))] + [digest([ph[0]])]
+    whole = [digest([x]) for x in (pos, st, np.asarray(exc, dtype=np.uint8))] + [digest([ph[m]]) for m in range(len(ph))]
     del pos, st, exc, ph
-    cut = 3_333_333
+    cut = n // 3
     a, b = run(0, cut), run(cut, n)
     halves = [digest([a[k], b[k]]) for k in (1, 3)] + [digest([np.asarray(a[4], dtype=np.uint8), np.asarray(b[4], dtype=np.uint8)])]
-    halves.append(digest([a[2][0], b[2][0]]))
+    halves += [digest([a[2][m], b[2][m]]) for m in range(len(a[2]))]
     assert halves == whole
