@@ -394,25 +394,34 @@ def test_a_grid_that_is_not_the_references_linspace_takes_the_checked_traversal(
         _assert_identical(gpu, ref)
 
 
-@pytest.mark.parametrize("workload,n,t_mid,t_end", [("c5b", 10_000_000, 130, 300), ("c4", 10_000_000, 130, 300),
-                                                     ("c3", 1_000_000, 130, 300), ("c2", 1_000_000, 400, 1000)])
-def test_full_size_sample_equals_the_oracle_and_the_partition_does_not_matter(lib, oracle_exact, workload, n, t_mid, t_end):
+_FULL_SIZE_POSITIONS = {}
+
+
+@pytest.mark.parametrize("workload,n,n_meas,t_mid,t_end", [
+    ("c5b", 10_000_000, 1, 130, 300), ("c5b", 10_000_000, 4, 130, 300), ("c5b", 10_000_000, 8, 130, 300),
+    ("c4", 10_000_000, 1, 130, 300), ("c3", 1_000_000, 1, 130, 300), ("c2", 1_000_000, 32, 400, 1000)])
+def test_full_size_sample_equals_the_oracle_and_the_partition_does_not_matter(lib, oracle_exact, workload, n, n_meas, t_mid, t_end):
     """BASELINE sizes (configs C5b, C4, C3, C2): all the walkers of the bench workload for the first steps of its
     waveform (C2: all of it), in two calls.  (i) 514 walkers drawn from all over the shard are bit-identical -
     position, phases, RNG state, iter_exc - to the oracle run on them alone from the same initial position and RNG
     state (walkers are independent, so a sample pins the full-size run: mesh - both walker groups, the spatial
-    pre-sort, the re-sorts, per-walker clocks and the restore of the order; C2 - the 32-accumulator kernel).  (ii) The
-    same walkers cut into two ragged shards with `first_walker` offsets give the same bytes as the one shard."""
+    pre-sort, the re-sorts, per-walker clocks and the restore of the order, with 1 and 4 measurements in registers and
+    with 8 through recorded positions; C2 - the 32-accumulator kernel).  (ii) The same walkers cut into two ragged
+    shards with `first_walker` offsets give the same bytes as the one shard."""
     import hashlib
 
     from disimpy_amd import simulations
     from oracle.oracle import STATE_DTYPE
 
-    w = bench.make_workload(workload, n)
+    w = bench.make_workload(workload, n, n_meas) if workload not in ("c1", "c2") else bench.make_workload(workload, n)
     sub, g, dt = w["substrate"], w["gradient"], w["dt"]
+    assert g.shape[0] == n_meas
     step_l = float(np.sqrt(6 * D * dt))
-    pos0, _ = simulations._initial_positions(n, sub, 123, True, 0)
-    pos0 = np.zeros((n, 3)) if pos0 is None else np.ascontiguousarray(pos0)
+    if (workload, n) not in _FULL_SIZE_POSITIONS:  # the mesh fill of 1e7 points takes a few seconds: once per workload
+        _FULL_SIZE_POSITIONS.clear()
+        pos0, _ = simulations._initial_positions(n, sub, 123, True, 0)
+        _FULL_SIZE_POSITIONS[(workload, n)] = np.zeros((n, 3)) if pos0 is None else np.ascontiguousarray(pos0)
+    pos0 = _FULL_SIZE_POSITIONS[(workload, n)]
 
     def run(a, b):
         with lib.Sim(b - a, g, dt, step_l, first_walker=a) as sim:
