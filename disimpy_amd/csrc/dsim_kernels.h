@@ -424,18 +424,23 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
             STAT_WAVE(3);
             scan_candidates(ms, (int)ms.cell_start[base], (int)ms.cell_start[base + 1], cb, tr0, step, min_d, closest, tie);
           } else {
-            const int k = 1 << lk;
-            const double sx = (double)k * ms.inv_hx, sy = (double)k * ms.inv_hy, sz = (double)k * ms.inv_hz;
-            const int a0 = micro_cell((double)cb.lox, xs[x], sx, k), a1 = micro_cell((double)cb.hix, xs[x], sx, k);
-            const int b0 = micro_cell((double)cb.loy, ys[y], sy, k), b1 = micro_cell((double)cb.hiy, ys[y], sy, k);
+            /* x, y: 2k half-cell units per subvoxel, a cell of two units at every unit but the last (dsim_mesh_host.h):
+             * the units u0 .. u1 of the box are covered by the cells at u0, u0 + 2, ... */
+            const int k = 1 << lk, k2 = 2 * k;
+            const double sx = (double)k2 * ms.inv_hx, sy = (double)k2 * ms.inv_hy, sz = (double)k * ms.inv_hz;
+            const int a0 = micro_cell((double)cb.lox, xs[x], sx, k2), a1 = micro_cell((double)cb.hix, xs[x], sx, k2);
+            const int b0 = micro_cell((double)cb.loy, ys[y], sy, k2), b1 = micro_cell((double)cb.hiy, ys[y], sy, k2);
             const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
-            for (int a = a0; a <= a1; a++)
-              for (int b = b0; b <= b1; b++) {
+            for (int a = a0;; a += 2) {
+              for (int b = b0;; b += 2) {
                 STAT_LANE(3);
                 STAT_WAVE(3);
-                const int c = base + (a * k + b) * k; /* the cells c0 .. c1 of this column: one run of records */
+                const int c = base + (min(a, k2 - 2) * k2 + min(b, k2 - 2)) * k; /* the cells c0 .. c1 of this column: one run of records */
                 scan_candidates(ms, (int)ms.cell_start[c + c0], (int)ms.cell_start[c + c1 + 1], cb, tr0, step, min_d, closest, tie);
+                if (b + 1 >= b1) break;
               }
+              if (a + 1 >= a1) break;
+            }
           }
         }
       }

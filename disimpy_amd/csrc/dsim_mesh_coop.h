@@ -77,7 +77,7 @@ struct CoopWave {
   uint2 first[64];                 /* every owner's first run {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell} */
   unsigned more[COOP_RUNQ_CAP - 64]; /* the other runs, by name only: owner | number of the run << 6              1.5 KB */
   int4 plan_a[64];                 /* what the runs of an owner are numbered over (RunPlan): a0, b0, c0, c1 ...          */
-  int2 plan_b[64];                 /*   ... first z unit, columns in y | z units << 8                              1.5 KB */
+  int2 plan_b[64];                 /*   ... first z unit, columns in y | z units << 8 | n0a << 16 | n0b << 24      1.5 KB */
   uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 30, owner | shifts << 6} (1c -> 2)  2.5 KB */
   unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
   unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6                                                   1.0 KB */
@@ -145,8 +145,9 @@ DSD float cull_margin(const float4 &q0, const float4 &q1, const float4 &q2, cons
   return __builtin_fmaxf(__builtin_fmaxf(g1, g2), side);
 }
 
-/* the fine cells of a pass: global fine coordinates (subvoxel * k + cell, any periodic image) per axis, both ends
- * inclusive, already clamped into the first / last subvoxel of the reference's range */
+/* the fine grid coordinates of a pass, any periodic image, both ends inclusive, already clamped into the first / last
+ * subvoxel of the reference's range: along z cells (subvoxel * k + cell); along x and y - where the cells of a k > 1
+ * grid overlap, dsim_mesh_host.h - half-cell UNITS (subvoxel * 2k + unit; k == 1: the subvoxels themselves) */
 struct FineRange {
   int a0, a1, b0, b1, c0, c1;
 };
@@ -218,8 +219,9 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
       sw.ulz = ul_subvoxel_overlap_periodic(zs, ms.nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
     }
   }
-  fine_limits(tn0, tx0, q0, sw.llx, sw.ulx, ms.lk, fr.a0, fr.a1);
-  fine_limits(tn1, tx1, q1, sw.lly, sw.uly, ms.lk, fr.b0, fr.b1);
+  const int lu = ms.lk > 0 ? ms.lk + 1 : 0; /* x, y: 2k units per subvoxel */
+  fine_limits(tn0, tx0, q0, sw.llx, sw.ulx, lu, fr.a0, fr.a1);
+  fine_limits(tn1, tx1, q1, sw.lly, sw.uly, lu, fr.b0, fr.b1);
   fine_limits(tn2, tx2, q2, sw.llz, sw.ulz, ms.lk, fr.c0, fr.c1);
 }
 
@@ -233,15 +235,29 @@ DSD void wrap_subvoxel(int s, int n, int &x, int &sn) {
 }
 
 /* The runs of a pass.  A run is a stretch of fine cells along z whose records are contiguous in mrec: inside one
- * subvoxel (lk > 0: its k cells of one (x, y) fine column) or, when the subvoxels themselves are the cells (lk == 0),
+ * subvoxel (lk > 0: its k cells of one (x, y) column of cells) or, when the subvoxels themselves are the cells (lk == 0),
  * inside one periodic image of the z axis (cell_start is indexed by the subvoxel, z-fastest).  The "z unit" is that
  * stretch - a subvoxel or an image.  The runs of an owner are numbered j = (ia * nb + ib) * nc + iz over its na x nb
- * fine columns and nc z units; any lane can work out run j from the plan alone. */
+ * columns and nc z units; any lane can work out run j from the plan alone.
+ *
+ * Columns along x (y alike), lk > 0: the box covers the units a0 .. a1 (2k units per subvoxel) and the cells are two
+ * units wide, one at every unit but the last of a subvoxel.  In the first subvoxel the columns are the cells at
+ * a0, a0 + 2, ... (n0a of them; a cell that would start at the subvoxel's last unit is the one before it), every
+ * further subvoxel of the range is entered at its unit 0 with the cells 0, 2, 4, ...  A box narrower than a unit - the
+ * rule: units are at least 0.75 step lengths wide - covers at most two units: ONE column unless it straddles a subvoxel. */
 struct RunPlan {
-  int a0, b0, c0, c1; /* first fine column, fine z range */
+  int a0, b0, c0, c1; /* first unit along x and y, fine z range */
   int zu0;            /* first z unit */
   int nb, nc;         /* columns along y, z units */
+  int n0a, n0b;       /* lk > 0: columns inside the first subvoxel along x, y */
 };
+
+/* columns of the unit range [u0, u1] on an axis with 1 << lu units per subvoxel, and how many lie in the first subvoxel */
+DSD int plan_columns(int u0, int u1, int lu, int &n_first) {
+  const int next = ((u0 >> lu) + 1) << lu; /* first unit of the following subvoxel */
+  n_first = ((min(u1, next - 1) - u0) >> 1) + 1;
+  return n_first + (u1 >= next ? ((u1 - next) >> 1) + 1 : 0);
+}
 
 /* number of runs of the pass (0: the reference's range is empty, nothing is visited), or -1 when the walker cannot be
  * queued: image shifts must fit 6 bits each, a run holds at most 16 cells, and no more than COOP_MAX_RUNS runs */
@@ -249,24 +265,42 @@ DSD int plan_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, 
   if (w.ulx <= w.llx || w.uly <= w.lly || w.ulz <= w.llz) return 0;
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
   if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return -1;
-  int zu1;
+  int zu1, na;
   if (ms.lk > 0) {
     rp.zu0 = w.llz, zu1 = w.ulz - 1;
+    na = plan_columns(f.a0, f.a1, ms.lk + 1, rp.n0a);
+    rp.nb = plan_columns(f.b0, f.b1, ms.lk + 1, rp.n0b);
   } else {
     if (w.ulz - w.llz > 16) return -1;
     int z;
     wrap_subvoxel(w.llz, nz, z, rp.zu0);
     wrap_subvoxel(w.ulz - 1, nz, z, zu1);
+    na = f.a1 - f.a0 + 1;
+    rp.nb = f.b1 - f.b0 + 1;
+    rp.n0a = rp.n0b = 0;
   }
-  const int na = f.a1 - f.a0 + 1;
   rp.a0 = f.a0, rp.b0 = f.b0, rp.c0 = f.c0, rp.c1 = f.c1;
-  rp.nb = f.b1 - f.b0 + 1, rp.nc = zu1 - rp.zu0 + 1;
+  rp.nc = zu1 - rp.zu0 + 1;
   if (na > COOP_MAX_RUNS || rp.nb > COOP_MAX_RUNS || rp.nc > COOP_MAX_RUNS) return -1;
   const int n = na * rp.nb * rp.nc;
   return n > COOP_MAX_RUNS ? -1 : n;
 }
 
-/* run j of an owner's plan as a queue entry {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell} */
+/* column i of an axis (plan_columns): the subvoxel (absolute, any image) and the cell inside it */
+DSD void plan_column(int u0, int n_first, int i, int lk, int &sv, int &cell) {
+  const int lu = lk + 1, um = (1 << lu) - 1;
+  if (i < n_first) {
+    const int g = u0 + 2 * i;
+    sv = g >> lu;
+    cell = min(g & um, um - 1);
+  } else {
+    const int r = i - n_first;
+    sv = (u0 >> lu) + 1 + (r >> lk);
+    cell = 2 * (r & ((1 << lk) - 1));
+  }
+}
+
+/* run j of an owner's plan as a queue entry {owner | shifts << 6 | (cells - 1) << 24, subvoxel * cell slots + first cell} */
 DSD uint2 make_run(const MeshDev &ms, int owner, const RunPlan &rp, int j) {
   const int lk = ms.lk, k = 1 << lk, km = k - 1;
   int ia = 0, ib = 0, iz = j;
@@ -277,10 +311,17 @@ DSD uint2 make_run(const MeshDev &ms, int owner, const RunPlan &rp, int j) {
     ib = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)rp.nc));
     iz = rem - ib * rp.nc;
   }
-  const int a = rp.a0 + ia, b = rp.b0 + ib, zu = rp.zu0 + iz;
+  const int zu = rp.zu0 + iz;
+  int sa, sb, ca = 0, cb = 0;
+  if (lk > 0) {
+    plan_column(rp.a0, rp.n0a, ia, lk, sa, ca);
+    plan_column(rp.b0, rp.n0b, ib, lk, sb, cb);
+  } else {
+    sa = rp.a0 + ia, sb = rp.b0 + ib;
+  }
   int x, snx, y, sny, z, snz, cs, ce;
-  wrap_subvoxel(a >> lk, ms.nx, x, snx);
-  wrap_subvoxel(b >> lk, ms.ny, y, sny);
+  wrap_subvoxel(sa, ms.nx, x, snx);
+  wrap_subvoxel(sb, ms.ny, y, sny);
   if (lk > 0) {
     wrap_subvoxel(zu, ms.nz, z, snz);
     cs = max(rp.c0, zu * k), ce = min(rp.c1, zu * k + km);
@@ -291,10 +332,11 @@ DSD uint2 make_run(const MeshDev &ms, int owner, const RunPlan &rp, int j) {
     z = cs - lo;
   }
   const unsigned sv = (unsigned)((x * ms.ny + y) * ms.nz + z);
-  const unsigned cell = (unsigned)(((((a & km) << lk) | (b & km)) << lk) | (cs & km));
+  /* cell slots of a subvoxel: (2k)^2 k, column-major with z fastest (lk == 0: the subvoxel is the cell) */
+  const unsigned cell = lk > 0 ? (unsigned)(((((ca << (lk + 1)) | cb) << lk) | (cs & km))) : 0u;
   return make_uint2((unsigned)owner | ((unsigned)(snx + 32) << 6) | ((unsigned)(sny + 32) << 12) | ((unsigned)(snz + 32) << 18) |
                         ((unsigned)(ce - cs) << 24),
-                    (sv << (3 * lk)) + cell);
+                    lk > 0 ? (sv << (3 * lk + 2)) + cell : sv);
 }
 
 /* Stage 3: one trip of fp64 tests over the survivors [base, base + count) of the pool, count <= 64:
@@ -405,7 +447,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
    * them with __shfl, so every lane has to be active wherever a shuffle is executed. */
   CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   int n_runs = 0;
-  RunPlan rp = {0, 0, 0, 0, 0, 1, 1};
+  RunPlan rp = {0, 0, 0, 0, 0, 1, 1, 0, 0};
   const MeshDev &ms = p.mesh;
   if (act) {
     iter_idx++;
@@ -444,7 +486,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       if (n_runs > 1)
       {
         W->plan_a[lane] = make_int4(rp.a0, rp.b0, rp.c0, rp.c1);
-        W->plan_b[lane] = make_int2(rp.zu0, rp.nb | (rp.nc << 8));
+        W->plan_b[lane] = make_int2(rp.zu0, rp.nb | (rp.nc << 8) | (rp.n0a << 16) | (rp.n0b << 24));
       }
       for (int j = 1; j < n_runs; j++) W->more[extra + j - 1] = (unsigned)lane | ((unsigned)j << 6);
     }
@@ -460,7 +502,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const MeshDev &ms = fresh_params<KA>(p_arg).mesh;
     const double Lx = ms.x1, Ly = ms.y1, Lz = ms.z1; /* = xs[nx], ys[ny], zs[nz] */
     const int lk = ms.lk;
-    const unsigned cmask = (1u << (3 * lk)) - 1u;
+    const int lcs = 3 * lk + 2;                 /* log2 of the cell slots per subvoxel, lk > 0 */
+    const unsigned cmask = (1u << lcs) - 1u;
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     int cursor = 0;
     int n_items = 0;        /* items waiting in the queue (wave-uniform) */
@@ -479,7 +522,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             const int o = (int)(m & 63u);
             const int4 pa = W->plan_a[o];
             const int2 pb = W->plan_b[o];
-            const RunPlan q = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y & 255, pb.y >> 8};
+            const RunPlan q = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y & 255, (pb.y >> 8) & 255, (pb.y >> 16) & 255, (pb.y >> 24) & 255};
             e = make_run(ms, o, q, (int)(m >> 6));
           }
         }
@@ -490,7 +533,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           int cell = (int)e.y;
           bool some = true;
           if (lk > 0) {
-            const int base = ms.sv_base[e.y >> (3 * lk)];
+            const int base = ms.sv_base[e.y >> lcs];
             some = base >= 0;
             cell = base + (int)(e.y & cmask);
           }

@@ -77,7 +77,8 @@ static void free_mesh(DevMesh &m) {
   m = DevMesh();
 }
 
-/* Does the triangle reach micro-cell (a, b, c) of a k^3 grid?  Conservative separating-axis test
+/* Does the triangle reach the cell that spans the units [abc, abc + span) of a subvoxel cut into nun units per axis
+ * (x, y: cells of two half-cell units at every unit, i.e. overlapping; z: one unit per cell)?  Conservative separating-axis test
  * (Akenine-Moller) in double precision against the cell inflated by 1e-6 of its size - far more
  * than any rounding of the test or of micro_cell().  Cells on the border of the grid extend to
  * infinity outwards, because the clamped cell map sends every coordinate beyond the subvoxel to
@@ -86,14 +87,14 @@ static void free_mesh(DevMesh &m) {
  * alone lists a triangle in every cell its box touches: on the neuron that is twice as many
  * records per cell as the triangles that actually pass through it. */
 static bool triangle_reaches_cell(const double *const tv[3], const float *tlo, const float *thi, const double org[3],
-                                  const double scale[3], const int abc[3], int k) {
+                                  const double scale[3], const int abc[3], const int span[3], const int nun[3]) {
   double c[3], h[3];
   for (int ax = 0; ax < 3; ax++) {
-    const double w = 1.0 / scale[ax], m = 1e-6 * w;
-    double lo = org[ax] + abc[ax] * w - m, hi = org[ax] + (abc[ax] + 1) * w + m;
+    const double w = 1.0 / scale[ax], m = 1e-6 * w * span[ax];
+    double lo = org[ax] + abc[ax] * w - m, hi = org[ax] + (abc[ax] + span[ax]) * w + m;
     const double blo = (double)tlo[ax] - m, bhi = (double)thi[ax] + m;
     if (abc[ax] == 0 || lo < blo) lo = blo;         /* border cell: unbounded below; clip to the triangle's box */
-    if (abc[ax] == k - 1 || hi > bhi) hi = bhi;
+    if (abc[ax] + span[ax] == nun[ax] || hi > bhi) hi = bhi;
     if (!(hi > lo)) return true; /* cannot happen for a cell of the triangle's range; keep the record */
     c[ax] = 0.5 * (lo + hi);
     h[ax] = 0.5 * (hi - lo);
@@ -287,17 +288,17 @@ static void build_clearance_map(const double *vertices, const int64_t *faces, in
  * own box.  Sutherland-Hodgman clipping in double precision; the result is pushed outwards by another 1e-6 cell
  * sizes (rounding of the clipping) and intersected with the triangle's box.  Returns false (keep the triangle's box)
  * when the clipped polygon comes out empty, which only rounding can cause for a registered triangle. */
-static bool clipped_triangle_box(const double *const tv[3], const double org[3], const double scale[3], const int abc[3], int k,
-                                 double lo[3], double hi[3]) {
+static bool clipped_triangle_box(const double *const tv[3], const double org[3], const double scale[3], const int abc[3],
+                                 const int span[3], const int nun[3], double lo[3], double hi[3]) {
   double poly[16][3], tmp[16][3];
   int n = 3;
   for (int q = 0; q < 3; q++)
     for (int ax = 0; ax < 3; ax++) poly[q][ax] = tv[q][ax];
   for (int ax = 0; ax < 3 && n > 0; ax++) {
-    const double w = 1.0 / scale[ax], m = 1e-6 * w;
+    const double w = 1.0 / scale[ax], m = 1e-6 * w * span[ax];
     for (int side = 0; side < 2 && n > 0; side++) {
-      if ((side == 0 && abc[ax] == 0) || (side == 1 && abc[ax] == k - 1)) continue; /* border cell: unbounded */
-      const double bound = side == 0 ? org[ax] + abc[ax] * w - m : org[ax] + (abc[ax] + 1) * w + m;
+      if ((side == 0 && abc[ax] == 0) || (side == 1 && abc[ax] + span[ax] == nun[ax])) continue; /* border cell: unbounded */
+      const double bound = side == 0 ? org[ax] + abc[ax] * w - m : org[ax] + (abc[ax] + span[ax]) * w + m;
       int out = 0;
       for (int q = 0; q < n; q++) {
         const double *p0 = poly[q], *p1 = poly[(q + 1) % n];
@@ -320,7 +321,7 @@ static bool clipped_triangle_box(const double *const tv[3], const double org[3],
   }
   if (n == 0) return false;
   for (int ax = 0; ax < 3; ax++) {
-    const double m = 1e-6 / scale[ax];
+    const double m = 1e-6 * span[ax] / scale[ax];
     lo[ax] = hi[ax] = poly[0][ax];
     for (int q = 1; q < n; q++) {
       lo[ax] = std::min(lo[ax], poly[q][ax]);
@@ -394,16 +395,26 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   }
   /* Fine grid.  The reference's candidate set of a subvoxel is its whole list (up to 88 triangles per 4.3 um
    * subvoxel on the neuron), and a wavefront pays for its worst lane.  Every NON-EMPTY reference subvoxel is
-   * therefore cut into k^3 cells, k = 2^lk the same for the whole mesh, so that a walker can name the cells its
-   * segment touches by arithmetic alone (global fine coordinate = subvoxel * k + cell; no look-up per subvoxel
-   * before the cells are known).  Cell c of subvoxel s lists the references OF s whose triangle reaches c; the
-   * border cells of a subvoxel extend to infinity outwards (the query clamps its cell range into the subvoxel), so
-   * whatever the reference lists in s is found through s - the exactness argument never leans on the reference's
-   * index being geometrically complete.  48-byte records {AABB of the triangle's part inside the cell, supporting
-   * plane in float32, triangle, position in the reference's list}; the cells of one subvoxel are stored z-fastest
-   * and their records back to back, so a run of cells along z is ONE contiguous range of records:
+   * therefore cut into cells, k = 2^lk per axis the same for the whole mesh, so that a walker can name the cells its
+   * segment touches by arithmetic alone (no look-up per subvoxel before the cells are known).  Cell c of subvoxel s
+   * lists the references OF s whose triangle reaches c; the border cells of a subvoxel extend to infinity outwards
+   * (the query clamps its cell range into the subvoxel), so whatever the reference lists in s is found through s -
+   * the exactness argument never leans on the reference's index being geometrically complete.
+   *
+   * [r4] Along x and y the cells OVERLAP: an axis of a subvoxel is cut into 2k half-cell "units" and there is a cell
+   * of two units at EVERY unit (cell i = units i and i + 1, i = 0 .. 2k - 2).  A segment's box is narrower than a unit
+   * on almost every pass (units are >= 0.75 step lengths and the box of a segment is |direction cosine| x what is left
+   * of the step), so it covers at most two units per axis and lies inside ONE cell: one run of records per pass instead
+   * of the 1.6 the disjoint cells of round 3 needed (a box that straddles a cell face had to read both neighbours'
+   * lists: 13.8 records and 1.6 look-ups per pass on the refined neuron, 2.2 runs per step; now the list of the one
+   * cell around it).  Boxes wider than two units take cells i, i + 2, ...  The price is memory: (2k)^2 k cell slots per
+   * non-empty subvoxel (slot 2k - 1 of an axis is never used: shifts instead of multiplications) and about 2.5 times
+   * the records.  Along z the cells are disjoint, stored fastest with their records back to back, so a run of cells
+   * along z is ONE contiguous range of records.  48-byte records {AABB of the triangle's part inside the cell,
+   * supporting plane in float32, triangle, position in the reference's list}:
    *     sv_base[s]           first cell of subvoxel s in cell_start, -1 for an empty subvoxel
-   *                          (lk == 0: not used, cell_start is indexed by s itself)
+   *                          (lk == 0: not used, cell_start is indexed by s itself, nothing overlaps)
+   *     cell                 sv_base[s] + ((i * 2k + j) * k + c)
    *     cell_start[c .. c+r] records of the r cells c .. c+r-1: [cell_start[c], cell_start[c+r]) of mrec */
   double inv_h3[3];
   {
@@ -443,12 +454,16 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   const double met = sum_n > 0 ? sum_n2 / sum_n : 0.0;
   int lk = met <= micro_t[0] ? 0 : (met <= micro_t[1] ? 1 : (met <= micro_t[2] ? 2 : (met <= micro_t[3] ? 3 : 4)));
   while (lk > 0 && sub_min / (double)(1 << lk) < micro_min_cell * step_l) lk--;
-  while (lk > 0 && ((double)n_nonempty * (double)(1 << (3 * lk)) > (double)(1 << 30) || (double)n_sub * (double)(1 << (3 * lk)) >= 4294967296.0)) lk--;
+  /* cell slots per subvoxel: 4 k^3 (x and y in 2k units) */
+  while (lk > 0 && ((double)n_nonempty * 4.0 * (double)(1 << (3 * lk)) > (double)(1 << 30) || (double)n_sub * 4.0 * (double)(1 << (3 * lk)) >= 4294967296.0)) lk--;
   const int k = 1 << lk;
+  /* units, cell span and cell slots per axis */
+  const int nun[3] = {lk > 0 ? 2 * k : 1, lk > 0 ? 2 * k : 1, k}, span[3] = {lk > 0 ? 2 : 1, lk > 0 ? 2 : 1, 1};
+  const size_t slots = (size_t)nun[0] * nun[1] * nun[2];
   std::vector<int32_t> sv_base((size_t)(lk > 0 ? n_sub : 1), -1);
   std::vector<uint32_t> cell_start;
   std::vector<float4> mrec;
-  cell_start.reserve((size_t)(lk > 0 ? n_nonempty * k * k * k : n_sub) + 1);
+  cell_start.reserve((size_t)(lk > 0 ? n_nonempty * slots : n_sub) + 1);
   {
     std::vector<std::vector<int32_t>> cells;
     std::vector<float> lo3, hi3;
@@ -460,8 +475,8 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       const int64_t sx = s / (n_sv[1] * n_sv[2]), sy = (s / n_sv[2]) % n_sv[1], sz = s % n_sv[2];
       const double org[3] = {xs[sx], ys[sy], zs[sz]};
-      const double scale[3] = {(double)k * inv_h3[0], (double)k * inv_h3[1], (double)k * inv_h3[2]};
-      cells.assign((size_t)k * k * k, std::vector<int32_t>());
+      const double scale[3] = {(double)nun[0] * inv_h3[0], (double)nun[1] * inv_h3[1], (double)nun[2] * inv_h3[2]}; /* units per metre */
+      cells.assign(slots, std::vector<int32_t>());
       lo3.assign((size_t)n_s * 3, 0.f);
       hi3.assign((size_t)n_s * 3, 0.f);
       for (int i = begin; i < end; i++) {
@@ -474,8 +489,10 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
           float hi = std::nextafter((float)mx, std::numeric_limits<float>::infinity());
           lo3[(size_t)(i - begin) * 3 + ax] = lo;
           hi3[(size_t)(i - begin) * 3 + ax] = hi;
-          c0[ax] = micro_cell((double)lo, org[ax], scale[ax], k);
-          c1[ax] = micro_cell((double)hi, org[ax], scale[ax], k);
+          /* units the triangle's box touches -> the cells that hold one of them: cell q spans units q .. q + span - 1 */
+          const int u0 = micro_cell((double)lo, org[ax], scale[ax], nun[ax]), u1 = micro_cell((double)hi, org[ax], scale[ax], nun[ax]);
+          c0[ax] = std::max(0, u0 - (span[ax] - 1));
+          c1[ax] = std::min(u1, nun[ax] - span[ax]);
         }
         const double *tv[3] = {&vertices[fc[0] * 3], &vertices[fc[1] * 3], &vertices[fc[2] * 3]};
         const float *tlo = &lo3[(size_t)(i - begin) * 3], *thi = &hi3[(size_t)(i - begin) * 3];
@@ -483,14 +500,14 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
           for (int b = c0[1]; b <= c1[1]; b++)
             for (int c = c0[2]; c <= c1[2]; c++) {
               const int abc[3] = {a, b, c};
-              if (k > 1 && !triangle_reaches_cell(tv, tlo, thi, org, scale, abc, k)) continue;
-              cells[((size_t)a * k + b) * k + c].push_back(i);
+              if (k > 1 && !triangle_reaches_cell(tv, tlo, thi, org, scale, abc, span, nun)) continue;
+              cells[((size_t)a * nun[1] + b) * nun[2] + c].push_back(i);
             }
       }
       if (lk > 0) sv_base[s] = (int32_t)cell_start.size();
       for (size_t ci = 0; ci < cells.size(); ci++) {
         auto &cl = cells[ci];
-        const int abc[3] = {(int)(ci / ((size_t)k * k)), (int)((ci / k) % k), (int)(ci % k)};
+        const int abc[3] = {(int)(ci / ((size_t)nun[1] * nun[2])), (int)((ci / nun[2]) % nun[1]), (int)(ci % nun[2])};
         cell_start.push_back((uint32_t)(mrec.size() / 3));
         for (int32_t i : cl) {
           float lo[3], hi[3];
@@ -499,7 +516,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
             const int64_t *fc3 = &faces[(size_t)refs[i] * 3];
             const double *tv[3] = {&vertices[fc3[0] * 3], &vertices[fc3[1] * 3], &vertices[fc3[2] * 3]};
             double clo[3], chi[3];
-            if (clipped_triangle_box(tv, org, scale, abc, k, clo, chi))
+            if (clipped_triangle_box(tv, org, scale, abc, span, nun, clo, chi))
               for (int ax = 0; ax < 3; ax++) {
                 const float l = std::nextafter((float)clo[ax], -std::numeric_limits<float>::infinity());
                 const float h2 = std::nextafter((float)chi[ax], std::numeric_limits<float>::infinity());

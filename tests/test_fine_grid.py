@@ -37,6 +37,10 @@ def _substrates():
 def test_fine_grid_is_complete(lib, name, sub, step_l):
     fg = lib.mesh_fine_grid(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices, step_l)
     lk, k = fg["lk"], 1 << fg["lk"]
+    # k > 1: along x and y a subvoxel has 2k half-cell units and a cell of two units at every unit but the last (the
+    # cells overlap, dsim_mesh_host.h); the slots of a subvoxel are (2k)^2 k, z fastest
+    ku = 2 * k if lk > 0 else 1
+    slots = ku * ku * k
     cs, tri, pos, box = fg["cell_start"].astype(np.int64), fg["tri"], fg["pos"], fg["box"]
     svi, refs = np.asarray(sub.subvoxel_indices), np.asarray(sub.triangle_indices)
     n_sub = int(np.prod(sub.n_sv))
@@ -47,7 +51,7 @@ def test_fine_grid_is_complete(lib, name, sub, step_l):
     if lk > 0:
         assert lk >= 1 and np.array_equal(fg["sv_base"] < 0, empty)
         base = fg["sv_base"].astype(np.int64)
-        assert len(cs) - 1 == (~empty).sum() * k ** 3
+        assert len(cs) - 1 == (~empty).sum() * slots
     else:
         base = np.arange(n_sub, dtype=np.int64)
         assert len(cs) - 1 == n_sub
@@ -55,7 +59,7 @@ def test_fine_grid_is_complete(lib, name, sub, step_l):
     rec_cell = np.repeat(np.arange(len(cs) - 1), np.diff(cs))
     owner = np.full(len(cs) - 1, -1, dtype=np.int64)
     for s in np.flatnonzero(~empty):
-        owner[base[s] : base[s] + k ** 3] = s
+        owner[base[s] : base[s] + slots] = s
     rec_sv = owner[rec_cell]
     assert np.all((pos >= svi[rec_sv, 0]) & (pos < svi[rec_sv, 1]))
     seen = np.zeros(len(refs), dtype=bool)
@@ -79,17 +83,26 @@ def test_fine_grid_is_complete(lib, name, sub, step_l):
         org = np.array([sub.xs[sx], sub.ys[sy], sub.zs[sz]])
         w = rng.dirichlet(np.ones(3), size=8)
         pts = w @ V[F[t]]
-        loc = np.clip(np.floor((pts - org) / h * k).astype(np.int64), 0, k - 1)
-        for p, (a, b, c) in zip(pts, loc):
-            cell = base[s] + (a * k + b) * k + c
-            key = int(cell)
-            if key not in cell_sets:
-                cell_sets[key] = {int(q): r for r, q in zip(range(cs[cell], cs[cell + 1]), pos[cs[cell] : cs[cell + 1]])}
-            assert int(i) in cell_sets[key], "%s: list entry %d (triangle %d, subvoxel %d) missing from cell %s of its subvoxel" % (name, i, t, s, (a, b, c))
-            checked += 1
-            if np.all(p >= org) and np.all(p <= org + h):
-                bx = box[cell_sets[key][int(i)]].astype(np.float64)
-                tol = 1e-6 * h.max()
-                assert np.all(p >= bx[:3] - tol) and np.all(p <= bx[3:] + tol), (name, i, p, bx)
-                inside += 1
+        per_axis = np.array([ku, ku, k])
+        loc = np.clip(np.floor((pts - org) / h * per_axis).astype(np.int64), 0, per_axis - 1)
+        for p, (ua, ub, c) in zip(pts, loc):
+            # EVERY cell that holds the point's unit must list the triangle: the traversal may come through any of them
+            cells_a = [q for q in (ua - 1, ua) if 0 <= q <= ku - 2] if lk > 0 else [0]
+            cells_b = [q for q in (ub - 1, ub) if 0 <= q <= ku - 2] if lk > 0 else [0]
+            for a in cells_a:
+                for b in cells_b:
+                    cell = base[s] + (a * ku + b) * k + c
+                    key = int(cell)
+                    if key not in cell_sets:
+                        cell_sets[key] = {int(q): r for r, q in zip(range(cs[cell], cs[cell + 1]), pos[cs[cell] : cs[cell + 1]])}
+                    assert int(i) in cell_sets[key], "%s: list entry %d (triangle %d, subvoxel %d) missing from cell %s of its subvoxel" % (name, i, t, s, (a, b, c))
+                    checked += 1
+                    if np.all(p >= org) and np.all(p <= org + h):
+                        bx = box[cell_sets[key][int(i)]].astype(np.float64)
+                        tol = 1e-6 * h.max()
+                        assert np.all(p >= bx[:3] - tol) and np.all(p <= bx[3:] + tol), (name, i, p, bx)
+                        inside += 1
+    if lk > 0:  # the unused slots (a cell cannot start at the last unit of an axis) are empty
+        n_rec = np.diff(cs).reshape(-1, ku, ku, k)
+        assert n_rec[:, ku - 1].sum() == 0 and n_rec[:, :, ku - 1].sum() == 0
     assert checked > 1000 and inside > 100
