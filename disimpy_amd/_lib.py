@@ -20,6 +20,7 @@ SYMBOLS = (
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
     "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close", "dsim_mesh_fine_grid",
+    "dsim_create_multi", "dsim_shard_count",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -55,6 +56,9 @@ def load():
     lib.dsim_rng_init_device.argtypes = [_h, C.c_uint64]
     lib.dsim_create.argtypes = [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _f64p, _f64p,
                                 _f64p, C.c_double, C.c_double]
+    lib.dsim_create_multi.argtypes = [C.POINTER(_h), _i32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _f64p, _f64p,
+                                      _f64p, C.c_double, C.c_double]
+    lib.dsim_shard_count.argtypes = [_h]
     lib.dsim_destroy.argtypes = [_h]
     lib.dsim_set_positions.argtypes = [_h, _f64p]
     lib.dsim_set_rng_states.argtypes = [_h, _u64p]
@@ -204,9 +208,10 @@ def interval_sv_overlap(xs, x1, x2):
 
 
 class Sim:
-    """Owner of one ``dsim_handle`` (one walker shard on one GPU)."""
+    """Owner of one ``dsim_handle``: a range of walkers on one GPU or, with ``devices=[d0, d1, ...]``, cut into balanced
+    shards over several devices of this node behind the one handle (dsim_create_multi; a device may be named twice)."""
 
-    def __init__(self, n_walkers, gradient, dt, step_l, device=0, first_walker=0):
+    def __init__(self, n_walkers, gradient, dt, step_l, device=0, first_walker=0, devices=None):
         lib = load()
         if lib.dsim_device_count() <= 0:
             raise DsimError("no HIP device visible (need an AMD GPU with ROCm); there is no CPU fallback")
@@ -215,9 +220,19 @@ class Sim:
         self.n = int(n_walkers)
         gx, gy, gz = (np.ascontiguousarray(g[:, :, k]) for k in range(3))
         self._h = _h()
-        check(lib.dsim_create(C.byref(self._h), device, self.n, first_walker, self.M, self.T, p_f64(gx), p_f64(gy),
-                              p_f64(gz), dt, step_l))
+        if devices is not None and len(devices) > 1:
+            ids = np.ascontiguousarray(devices, dtype=np.int32)
+            check(lib.dsim_create_multi(C.byref(self._h), ids.ctypes.data_as(_i32p), len(ids), self.n, first_walker, self.M, self.T,
+                                        p_f64(gx), p_f64(gy), p_f64(gz), dt, step_l))
+        else:
+            if devices is not None and len(devices) == 1:
+                device = int(devices[0])
+            check(lib.dsim_create(C.byref(self._h), device, self.n, first_walker, self.M, self.T, p_f64(gx), p_f64(gy),
+                                  p_f64(gz), dt, step_l))
         self._lib = lib
+
+    def shard_count(self):
+        return int(self._lib.dsim_shard_count(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -245,7 +245,47 @@ struct dsim_sim {
   uint32_t *sort_hist[DSIM_MAX_GROUPS] = {}, *sort_offs[DSIM_MAX_GROUPS] = {};
   int sort_bits = 0;
   int orig_cur = 0;
+  /* multi-device handle (dsim_create_multi): the walkers [first, first + n) cut into balanced contiguous ranges, one
+   * single-device handle per range (shards[k] owns the walkers [shard_off[k], shard_off[k] + shards[k]->n) of this
+   * handle); a handle with shards owns no device memory itself - every entry point hands the call on to the shards,
+   * each on a host thread of its own */
+  std::vector<dsim_sim *> shards;
+  std::vector<int64_t> shard_off;
 };
+
+/* f(k, shard, first walker of the shard inside the handle) for every shard of a multi-device handle, concurrently (one
+ * host thread per shard: HIP's current device is per thread, and the calls block); the first failure is reported with
+ * the shard's own message */
+template <class F>
+static int multi_each(dsim_sim *h, F f) {
+  const int n = (int)h->shards.size();
+  std::vector<int> rc((size_t)n, DSIM_OK);
+  std::vector<std::string> msg((size_t)n);
+  auto work = [&](int k) {
+    rc[(size_t)k] = f(k, h->shards[(size_t)k], h->shard_off[(size_t)k]);
+    if (rc[(size_t)k] != DSIM_OK) msg[(size_t)k] = g_err; /* the worker thread's own message */
+  };
+  if (n == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; k++) th.emplace_back(work, k);
+    for (auto &t : th) t.join();
+  }
+  for (int k = 0; k < n; k++)
+    if (rc[(size_t)k] != DSIM_OK) return fail(rc[(size_t)k], "shard %d (device %d): %s", k, h->shards[(size_t)k]->device, msg[(size_t)k].c_str());
+  return DSIM_OK;
+}
+#define IS_MULTI(h) ((h) != nullptr && !(h)->shards.empty())
+/* hand a call on to every shard: `call` sees the shard as s_ and its first walker inside the handle as off_ */
+#define MULTI_FORWARD(h, ...)                                                         \
+  do {                                                                                \
+    if (IS_MULTI(h))                                                                  \
+      return multi_each((h), [&](int k_, dsim_sim *s_, int64_t off_) -> int {         \
+        (void)k_, (void)off_;                                                         \
+        return (__VA_ARGS__);                                                         \
+      });                                                                             \
+  } while (0)
 
 static int ensure_staging(dsim_sim *h, size_t bytes) {
   if (h->staging_bytes >= bytes) return DSIM_OK;
@@ -259,6 +299,11 @@ static int ensure_staging(dsim_sim *h, size_t bytes) {
 
 extern "C" int dsim_destroy(dsim_handle h) {
   if (!h) return DSIM_OK;
+  if (IS_MULTI(h)) {
+    for (dsim_sim *s : h->shards) (void)dsim_destroy(s);
+    delete h;
+    return DSIM_OK;
+  }
   (void)hipSetDevice(h->device);
   for (int b = 0; b < 2; b++) {
     if (h->x[b]) (void)hipFree(h->x[b]);
@@ -378,8 +423,46 @@ extern "C" int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int6
   return DSIM_OK;
 }
 
+extern "C" int dsim_create_multi(dsim_handle *out, const int32_t *device_ids, int32_t n_devices, int64_t n_walkers, int64_t first_walker,
+                                 int32_t M, int32_t T, const double *gx, const double *gy, const double *gz, double dt, double step_l) {
+  if (!out) return fail(DSIM_ERR_INVALID, "dsim_create_multi: out is NULL");
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 1024) return fail(DSIM_ERR_INVALID, "dsim_create_multi: bad device list");
+  if (n_walkers <= 0 || first_walker < 0) return fail(DSIM_ERR_INVALID, "dsim_create_multi: bad walker range");
+  dsim_sim *h = new dsim_sim();
+  h->device = device_ids[0];
+  h->n = n_walkers;
+  h->phase_stride = n_walkers;
+  h->first = first_walker;
+  h->M = M;
+  h->T = T;
+  h->dt = dt;
+  h->step_l = step_l;
+  /* balanced contiguous ranges: the first n % G shards own one walker more (disimpy_amd/sharding.py, shard_range) */
+  const int64_t base = n_walkers / n_devices, extra = n_walkers % n_devices;
+  for (int k = 0; k < n_devices; k++) {
+    const int64_t a = k * base + std::min<int64_t>(k, extra), cnt = base + (k < extra ? 1 : 0);
+    if (cnt == 0) continue; /* more devices than walkers */
+    dsim_sim *sh = nullptr;
+    const int rc = dsim_create(&sh, device_ids[k], cnt, first_walker + a, M, T, gx, gy, gz, dt, step_l);
+    if (rc != DSIM_OK) {
+      const std::string keep = g_err;
+      for (dsim_sim *q : h->shards) (void)dsim_destroy(q);
+      delete h;
+      return fail(rc, "dsim_create_multi: shard %d on device %d: %s", k, device_ids[k], keep.c_str());
+    }
+    h->shards.push_back(sh);
+    h->shard_off.push_back(a);
+  }
+  *out = h;
+  return DSIM_OK;
+}
+
+extern "C" int dsim_shard_count(dsim_handle h) { return h ? (IS_MULTI(h) ? (int)h->shards.size() : 1) : 0; }
+
 extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass, int32_t resort_steps,
                                int32_t gradient_source, int32_t mesh_traversal) {
+  MULTI_FORWARD(h, dsim_set_tuning(s_, block_size, tile_steps, meas_per_pass, resort_steps, gradient_source, mesh_traversal));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (block_size) {
     if (block_size < 64 || block_size > 256 || block_size % 64) return fail(DSIM_ERR_INVALID, "block_size must be 64, 128, 192 or 256");
@@ -401,6 +484,7 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
 static inline int grid_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
+  MULTI_FORWARD(h, pos ? dsim_set_positions(s_, pos + 3 * off_) : fail(DSIM_ERR_INVALID, "dsim_set_positions: null argument"));
   if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_set_positions: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 3 * sizeof(double));
@@ -413,6 +497,7 @@ extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
 }
 
 extern "C" int dsim_get_positions(dsim_handle h, double *pos) {
+  MULTI_FORWARD(h, pos ? dsim_get_positions(s_, pos + 3 * off_) : fail(DSIM_ERR_INVALID, "dsim_get_positions: null argument"));
   if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_get_positions: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 3 * sizeof(double));
@@ -425,6 +510,7 @@ extern "C" int dsim_get_positions(dsim_handle h, double *pos) {
 }
 
 extern "C" int dsim_set_rng_states(dsim_handle h, const uint64_t *st) {
+  MULTI_FORWARD(h, st ? dsim_set_rng_states(s_, st + 2 * off_) : fail(DSIM_ERR_INVALID, "dsim_set_rng_states: null argument"));
   if (!h || !st) return fail(DSIM_ERR_INVALID, "dsim_set_rng_states: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 2 * sizeof(uint64_t));
@@ -437,6 +523,7 @@ extern "C" int dsim_set_rng_states(dsim_handle h, const uint64_t *st) {
 }
 
 extern "C" int dsim_get_rng_states(dsim_handle h, uint64_t *st) {
+  MULTI_FORWARD(h, st ? dsim_get_rng_states(s_, st + 2 * off_) : fail(DSIM_ERR_INVALID, "dsim_get_rng_states: null argument"));
   if (!h || !st) return fail(DSIM_ERR_INVALID, "dsim_get_rng_states: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 2 * sizeof(uint64_t));
@@ -449,6 +536,7 @@ extern "C" int dsim_get_rng_states(dsim_handle h, uint64_t *st) {
 }
 
 extern "C" int dsim_rng_init_device(dsim_handle h, uint64_t seed) {
+  MULTI_FORWARD(h, dsim_rng_init_device(s_, seed));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (((uint64_t)h->first + (uint64_t)h->n) >> 47) return fail(DSIM_ERR_INVALID, "walker index range too large");
   HIP_TRY(hipSetDevice(h->device));
@@ -466,6 +554,16 @@ extern "C" int dsim_rng_init_device(dsim_handle h, uint64_t seed) {
 }
 
 extern "C" int dsim_get_phases(dsim_handle h, double *phases) {
+  if (IS_MULTI(h)) {
+    if (!phases) return fail(DSIM_ERR_INVALID, "dsim_get_phases: null argument");
+    return multi_each(h, [&](int, dsim_sim *sh, int64_t off) -> int {
+      std::vector<double> part((size_t)sh->M * (size_t)sh->n);
+      const int rc = dsim_get_phases(sh, part.data());
+      if (rc) return rc;
+      for (int m = 0; m < sh->M; m++) memcpy(phases + (size_t)m * (size_t)h->n + (size_t)off, part.data() + (size_t)m * (size_t)sh->n, (size_t)sh->n * sizeof(double));
+      return DSIM_OK;
+    });
+  }
   if (!h || !phases) return fail(DSIM_ERR_INVALID, "dsim_get_phases: null argument");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(phases, h->phase, (size_t)h->M * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -477,6 +575,16 @@ extern "C" int dsim_get_phases(dsim_handle h, double *phases) {
  * stream into one of two device buffers, crosses PCIe on the copy stream into one of two pinned buffers, and is copied
  * out by the host while block k + 1 is already on its way. */
 extern "C" int dsim_get_all_signals(dsim_handle h, double *signals) {
+  if (IS_MULTI(h)) {
+    if (!signals) return fail(DSIM_ERR_INVALID, "dsim_get_all_signals: null argument");
+    return multi_each(h, [&](int, dsim_sim *sh, int64_t off) -> int {
+      std::vector<double> part((size_t)sh->M * (size_t)sh->n);
+      const int rc = dsim_get_all_signals(sh, part.data());
+      if (rc) return rc;
+      for (int m = 0; m < sh->M; m++) memcpy(signals + (size_t)m * (size_t)h->n + (size_t)off, part.data() + (size_t)m * (size_t)sh->n, (size_t)sh->n * sizeof(double));
+      return DSIM_OK;
+    });
+  }
   if (!h || !signals) return fail(DSIM_ERR_INVALID, "dsim_get_all_signals: null argument");
   HIP_TRY(hipSetDevice(h->device));
   const int64_t total = (int64_t)h->M * h->n;
@@ -531,6 +639,7 @@ extern "C" int dsim_get_all_signals(dsim_handle h, double *signals) {
 }
 
 extern "C" int dsim_get_iter_exc(dsim_handle h, uint8_t *exc) {
+  MULTI_FORWARD(h, exc ? dsim_get_iter_exc(s_, exc + off_) : fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument"));
   if (!h || !exc) return fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(exc, h->exc, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
@@ -539,6 +648,25 @@ extern "C" int dsim_get_iter_exc(dsim_handle h, uint8_t *exc) {
 }
 
 extern "C" int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_exceeded) {
+  if (IS_MULTI(h)) {
+    /* the shards' sums added up on the host in shard order (deterministic for a given device list) */
+    if (!out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
+    const size_t G = h->shards.size(), M = (size_t)h->M;
+    std::vector<double> c(G * M), sn(G * M);
+    std::vector<int64_t> ne(G, 0);
+    const int rc = multi_each(h, [&](int k, dsim_sim *sh, int64_t) -> int { return dsim_get_signal(sh, &c[(size_t)k * M], &sn[(size_t)k * M], &ne[(size_t)k]); });
+    if (rc) return rc;
+    int64_t total = 0;
+    for (size_t m = 0; m < M; m++) {
+      double a = 0, b = 0;
+      for (size_t k = 0; k < G; k++) a += c[k * M + m], b += sn[k * M + m];
+      out_cos[m] = a;
+      if (out_sin) out_sin[m] = b;
+    }
+    for (size_t k = 0; k < G; k++) total += ne[k];
+    if (n_exceeded) *n_exceeded = total;
+    return DSIM_OK;
+  }
   if (!h || !out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
   HIP_TRY(hipSetDevice(h->device));
   dim3 grid(h->sig_blocks, h->M);
@@ -622,6 +750,7 @@ extern "C" int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, c
 extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
                              const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                              const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs) {
+  MULTI_FORWARD(h, dsim_set_mesh(s_, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   return upload_mesh(h->mesh, h->stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs,
@@ -1435,6 +1564,7 @@ extern "C" int dsim_debug_timers(unsigned long long *out16) {
 #endif
 
 extern "C" int dsim_set_recording(dsim_handle h, int32_t enable) {
+  MULTI_FORWARD(h, dsim_set_recording(s_, enable));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   h->recording = enable != 0;
@@ -1500,7 +1630,22 @@ static int check_recorded_range(dsim_sim *h, const char *who, int32_t t_begin, i
   return DSIM_OK;
 }
 
+/* steps [t_begin, t_end) of every shard's recording into one component-major block [step][3][n] of the whole handle */
+static int multi_get_recorded(dsim_sim *h, int32_t t_begin, int32_t t_end, double *out) {
+  return multi_each(h, [&](int, dsim_sim *sh, int64_t off) -> int {
+    std::vector<double> part((size_t)(t_end - t_begin) * 3 * (size_t)sh->n);
+    const int rc = dsim_get_recorded(sh, t_begin, t_end, part.data());
+    if (rc) return rc;
+    for (size_t r = 0; r < (size_t)(t_end - t_begin) * 3; r++) memcpy(out + r * (size_t)h->n + (size_t)off, part.data() + r * (size_t)sh->n, (size_t)sh->n * sizeof(double));
+    return DSIM_OK;
+  });
+}
+
 extern "C" int dsim_get_recorded(dsim_handle h, int32_t t_begin, int32_t t_end, double *out) {
+  if (IS_MULTI(h)) {
+    if (!out || t_begin > t_end) return fail(DSIM_ERR_INVALID, "dsim_get_recorded: bad argument");
+    return t_begin == t_end ? DSIM_OK : multi_get_recorded(h, t_begin, t_end, out);
+  }
   if (!h || !out) return fail(DSIM_ERR_INVALID, "dsim_get_recorded: null argument");
   int rc = check_recorded_range(h, "dsim_get_recorded", t_begin, t_end);
   if (rc) return rc;
@@ -1645,6 +1790,24 @@ extern "C" int dsim_write_traj_line(const char *path, const double *positions_ao
 }
 
 extern "C" int dsim_write_traj(dsim_handle h, const char *path, int32_t t_begin, int32_t t_end, int32_t append) {
+  if (IS_MULTI(h)) {
+    /* a line of the file holds every walker of the handle: blocks of steps (<= 64 MB) are collected from the shards */
+    if (!path || t_begin > t_end) return fail(DSIM_ERR_INVALID, "dsim_write_traj: bad argument");
+    FILE *f = fopen(path, append ? "ab" : "wb");
+    if (!f) return fail(DSIM_ERR_STATE, "cannot open %s", path);
+    const size_t row = (size_t)3 * (size_t)h->n;
+    const int per = (int)std::max<size_t>(1, ((size_t)8 << 20) / row);
+    std::vector<double> buf;
+    int rc = DSIM_OK;
+    for (int t0 = t_begin; t0 < t_end && rc == DSIM_OK; t0 += per) {
+      const int cnt = std::min(per, t_end - t0);
+      buf.resize((size_t)cnt * row);
+      rc = multi_get_recorded(h, t0, t0 + cnt, buf.data());
+      if (rc == DSIM_OK) rc = write_traj_lines(f, h->n, cnt, buf.data(), row, buf.data(), buf.data() + h->n, buf.data() + 2 * h->n, 1);
+    }
+    if (fclose(f) != 0 && rc == DSIM_OK) rc = fail(DSIM_ERR_STATE, "trajectories file: close failed");
+    return rc;
+  }
   if (!h || !path) return fail(DSIM_ERR_INVALID, "dsim_write_traj: null argument");
   int rc = check_recorded_range(h, "dsim_write_traj", t_begin, t_end);
   if (rc) return rc;
@@ -1661,6 +1824,14 @@ extern "C" int dsim_write_traj(dsim_handle h, const char *path, int32_t t_begin,
 }
 
 extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) {
+  if (IS_MULTI(h)) { /* the shards run concurrently: the slowest one's time, everybody's launches */
+    double worst = 0;
+    int launches = 0;
+    for (dsim_sim *sh : h->shards) worst = std::max(worst, sh->last_ms), launches += sh->last_launches;
+    if (ms) *ms = worst;
+    if (n_launches) *n_launches = launches;
+    return DSIM_OK;
+  }
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_ms;
   if (n_launches) *n_launches = h->last_launches;
@@ -1668,6 +1839,19 @@ extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) 
 }
 
 extern "C" int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches) {
+  if (IS_MULTI(h)) {
+    double sum = 0;
+    int launches = 0;
+    for (dsim_sim *sh : h->shards) {
+      double q = 0;
+      int32_t nl = 0;
+      (void)dsim_last_walk_ms(sh, &q, &nl);
+      sum += q, launches += nl;
+    }
+    if (ms) *ms = sum;
+    if (n_launches) *n_launches = launches;
+    return DSIM_OK;
+  }
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_walk_ms;
   if (n_launches) {
@@ -1679,6 +1863,19 @@ extern "C" int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches)
 }
 
 extern "C" int dsim_last_walk_busy_ms(dsim_handle h, double *ms, int32_t *n_streams) {
+  if (IS_MULTI(h)) {
+    double worst = 0;
+    int streams = 0;
+    for (dsim_sim *sh : h->shards) {
+      double q = 0;
+      int32_t ns = 0;
+      (void)dsim_last_walk_busy_ms(sh, &q, &ns);
+      worst = std::max(worst, q), streams += ns;
+    }
+    if (ms) *ms = worst;
+    if (n_streams) *n_streams = streams;
+    return DSIM_OK;
+  }
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (ms) *ms = h->last_walk_busy_ms;
   if (n_streams) *n_streams = h->grp_walk_ev_used[0] > 0 ? h->last_groups : 1;
@@ -1692,12 +1889,14 @@ static int check_iter(int64_t max_iter, double eps) {
 }
 
 extern "C" int dsim_run_free(dsim_handle h, int32_t t_begin, int32_t t_end) {
+  MULTI_FORWARD(h, dsim_run_free(s_, t_begin, t_end));
   WalkParams p = {};
   p.max_iter = 1;
   return run_impl(h, GEOM_FREE, p, t_begin, t_end);
 }
 
 extern "C" int dsim_run_sphere(dsim_handle h, double radius, int64_t max_iter, double epsilon, int32_t t_begin, int32_t t_end) {
+  MULTI_FORWARD(h, dsim_run_sphere(s_, radius, max_iter, epsilon, t_begin, t_end));
   if (!(radius > 0)) return fail(DSIM_ERR_INVALID, "radius must be > 0");
   int rc = check_iter(max_iter, epsilon);
   if (rc) return rc;
@@ -1710,6 +1909,7 @@ extern "C" int dsim_run_sphere(dsim_handle h, double radius, int64_t max_iter, d
 
 extern "C" int dsim_run_cylinder(dsim_handle h, double radius, const double R[9], const double R_inv[9], int64_t max_iter,
                                  double epsilon, int32_t t_begin, int32_t t_end) {
+  MULTI_FORWARD(h, dsim_run_cylinder(s_, radius, R, R_inv, max_iter, epsilon, t_begin, t_end));
   if (!(radius > 0) || !R || !R_inv) return fail(DSIM_ERR_INVALID, "bad cylinder arguments");
   int rc = check_iter(max_iter, epsilon);
   if (rc) return rc;
@@ -1724,6 +1924,7 @@ extern "C" int dsim_run_cylinder(dsim_handle h, double radius, const double R[9]
 
 extern "C" int dsim_run_ellipsoid(dsim_handle h, const double semiaxes[3], const double R[9], const double R_inv[9],
                                   int64_t max_iter, double epsilon, int32_t t_begin, int32_t t_end) {
+  MULTI_FORWARD(h, dsim_run_ellipsoid(s_, semiaxes, R, R_inv, max_iter, epsilon, t_begin, t_end));
   if (!semiaxes || !R || !R_inv) return fail(DSIM_ERR_INVALID, "bad ellipsoid arguments");
   int rc = check_iter(max_iter, epsilon);
   if (rc) return rc;
@@ -1737,6 +1938,7 @@ extern "C" int dsim_run_ellipsoid(dsim_handle h, const double semiaxes[3], const
 }
 
 extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, double perm_prob, int32_t t_begin, int32_t t_end) {
+  MULTI_FORWARD(h, dsim_run_mesh(s_, max_iter, epsilon, perm_prob, t_begin, t_end));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (!h->mesh.set) return fail(DSIM_ERR_STATE, "dsim_run_mesh called before dsim_set_mesh");
   int rc = check_iter(max_iter, epsilon);

@@ -84,13 +84,25 @@ def fill_mesh_sharded(n_points, open_session, dist=None, device=None, walker_ran
             cap = min(n_points - have, (t1 - t0) * batch)
             if launches and have:
                 cap = min(cap, int(8.0 * have / launches * batch * (t1 - t0) / n_points) + 100_000)
+            # a failure on ONE rank (buffer overflow, a library error) must end the loop on EVERY rank: the status travels
+            # with the counts of the batch, nobody leaves the collective alone (the others would hang in it)
+            status, problem = 0, None
+            counts, pts = np.zeros(batch, dtype=np.int64), np.zeros((0, 3))
             if sess is not None:
-                counts, pts = sess.run(batch, cap)
-                if int(counts.sum()) > len(pts) and len(pts) < n_points - have:
-                    raise RuntimeError("fill_mesh_sharded: %d accepted points in one batch overflow the buffer of %d" % (counts.sum(), cap))
-            else:
-                counts, pts = np.zeros(batch, dtype=np.int64), np.zeros((0, 3))
-            all_counts = np.stack(_all_gather(counts, dist, device)) if world > 1 else counts[None, :]
+                try:
+                    counts, pts = sess.run(batch, cap)
+                    if int(counts.sum()) > len(pts) and len(pts) < n_points - have:
+                        status, problem = -1, "%d accepted points in one batch overflow the buffer of %d" % (counts.sum(), cap)
+                except Exception as e:  # noqa: BLE001 - reported below, on every rank
+                    status, problem = -2, "%s: %s" % (type(e).__name__, e)
+                    counts, pts = np.zeros(batch, dtype=np.int64), np.zeros((0, 3))
+            msg = np.concatenate([np.asarray(counts, dtype=np.int64), [status]])
+            gathered = np.stack(_all_gather(msg, dist, device)) if world > 1 else msg[None, :]
+            bad = np.flatnonzero(gathered[:, -1] < 0)
+            if len(bad):
+                raise RuntimeError("fill_mesh_sharded: rank %d failed (%s)" % (
+                    int(bad[0]), problem if problem is not None and rank in bad else "status %d" % gathered[bad[0], -1]))
+            all_counts = gathered[:, :-1]
             per_launch = all_counts.sum(axis=0)
             launch_base = have + np.concatenate([[0], np.cumsum(per_launch)[:-1]])
             mine = launch_base + all_counts[:rank].sum(axis=0)  # global row of my first point of every launch
@@ -130,11 +142,27 @@ def fill_mesh_sharded(n_points, open_session, dist=None, device=None, walker_ran
     return out
 
 
+def _gather_rows(arr, dist, device=None):
+    """Concatenation over the ranks (in rank order) of arrays that differ in their first dimension only."""
+    arr = np.ascontiguousarray(arr)
+    sizes = [int(x[0]) for x in _all_gather(np.array([len(arr)], dtype=np.int64), dist, device)]
+    width = max(sizes + [1])
+    pad = np.zeros((width,) + arr.shape[1:], dtype=arr.dtype)
+    pad[: len(arr)] = arr
+    return np.concatenate([part[:n] for part, n in zip(_all_gather(pad, dist, device), sizes)])
+
+
 def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123, quiet=True, max_iter=int(1e3),
-                       epsilon=1e-13, dist=None, device=None):
-    """``simulations.simulation`` with the walkers split over the ranks of the
-    initialised process group; every rank returns the same total signal
-    (sum of cos(phase) per measurement)."""
+                       epsilon=1e-13, dist=None, device=None, final_pos=False, all_signals=False):
+    """``simulations.simulation`` with the walkers split over the ranks of the initialised process group (one process
+    per GPU); every rank returns what the single-process call returns: the total signal (sum of cos(phase) per
+    measurement) or, ``all_signals``, the (M, n_walkers) per-walker signals; with ``final_pos`` also the (n_walkers, 3)
+    final positions - per-walker outputs gathered in walker order - and every rank raises the reference's warning
+    about walkers that exceeded ``max_iter`` with GLOBAL walker indices (disimpy/simulations.py:1406-1429).
+    (Inside one process ``simulations.simulation`` itself spreads the walkers over all visible GPUs; this entry is
+    for jobs that are launched as one process per GPU.)"""
+    import warnings
+
     from . import simulations
 
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
@@ -142,13 +170,30 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
     simulations._validate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, 128, max_iter)
     np.random.seed(seed)
     a, b = shard_range(n_walkers, rank, world)
+    M = gradient.shape[0]
     if b == a:  # more ranks than walkers: nothing to simulate here, but the collectives still need this rank
         if world > 1 and substrate.type == "mesh" and isinstance(substrate.init_pos, str) and substrate.init_pos in ("intra", "extra"):
             simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (a, b), dist=dist)  # the shared fill
-        M = gradient.shape[0]
-        c, s, nexc = reduce_signal(np.zeros(M), np.zeros(M), 0, dist, device)
-        return c
-    res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, max_iter, epsilon,
-                                device=device or 0, walker_range=(a, b), dist=dist if world > 1 else None)
+        res = {"cos": np.zeros(M), "sin": np.zeros(M), "n_exceeded": 0, "iter_exc": np.zeros(0, dtype=bool),
+               "all_signals": np.zeros((M, 0)), "positions": np.zeros((0, 3))}
+    else:
+        res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, max_iter, epsilon,
+                                    device=device or 0, walker_range=(a, b), dist=dist if world > 1 else None,
+                                    need_phases=bool(all_signals), need_positions=bool(final_pos))
     c, s, nexc = reduce_signal(res["cos"], res["sin"], res["n_exceeded"], dist, device)
-    return c
+    if nexc:  # rare: the flags of all walkers, for the warning text (same on every rank)
+        exc = _gather_rows(res["iter_exc"].astype(np.uint8), dist, device).astype(bool) if world > 1 else res["iter_exc"]
+        if np.any(exc):
+            warnings.warn(
+                "Maximum number of iterations was exceeded in the intersection "
+                + "check algorithm for walkers %s" % np.where(exc)[0]
+            )
+    signals = c
+    if all_signals:
+        signals = res["all_signals"]
+        if world > 1:
+            signals = np.ascontiguousarray(_gather_rows(np.ascontiguousarray(signals.T), dist, device).T)
+    if final_pos:
+        pos = res["positions"] if world == 1 else _gather_rows(res["positions"], dist, device)
+        return signals, pos
+    return signals

@@ -8,6 +8,7 @@ synchronisation per step, and the signal is reduced on the device instead of
 copying the (M, N) phase matrix to the host.  There is no CPU fallback.
 """
 import math
+import os
 import sys
 import warnings
 
@@ -217,9 +218,11 @@ def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=N
     * mesh, ``init_pos="uniform"`` (:1347): the first 3 b draws of the global NumPy stream;
     * mesh, ``init_pos="intra"/"extra"`` (:505-579): every launch of the reference's fill
       kernel appends its accepted points in thread order, so row i depends on the outcome
-      of all earlier threads and launches; each rank runs the whole device fill (4 to 30 s)
-      on its own GPU - in parallel, so the wall time equals the single-GPU case - and keeps
-      its rows."""
+      of all earlier threads and launches.  Thread t of every launch only ever needs RNG state t,
+      though: with an initialised process group the ranks share the fill - each runs the launches
+      over its range of the threads, the per-launch accepted counts are exchanged and every rank
+      ends up with its rows of the single-process sequence (sharding.fill_mesh_sharded); a single
+      process runs the whole fill on one device and keeps rows [a, b)."""
     a, b = (0, n_walkers) if walker_range is None else walker_range
     kind = substrate.type
     if kind == "free":
@@ -272,9 +275,20 @@ def _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1):
         sim.run_mesh(max_iter, epsilon, substrate.perm_prob, t0, t1)
 
 
+def _default_devices(n_gpu):
+    """The devices ``simulation()`` spreads its walkers over: every visible GPU, one balanced contiguous shard of
+    the walkers each (dsim_create_multi), unless DSIM_DEVICES names a list (e.g. ``0,0``: two shards on device 0)."""
+    env = os.environ.get("DSIM_DEVICES")
+    if env:
+        return [int(x) for x in env.split(",") if x.strip() != ""]
+    return list(range(max(1, n_gpu)))
+
+
 def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon, device=0,
-              walker_range=None, need_phases=False, need_positions=False, dist=None):
-    """Run walkers [a, b) = ``walker_range`` (default: all) on one GPU.
+              walker_range=None, need_phases=False, need_positions=False, dist=None, devices=None):
+    """Run walkers [a, b) = ``walker_range`` (default: all) on one GPU, or - ``devices`` a list of more than one
+    device - cut into balanced shards over several GPUs behind one multi-device handle (include/dsim.h,
+    dsim_create_multi: the shards run concurrently, per-walker outputs come back in order).
 
     Returns a dict with the device-reduced signal sums and, on request,
     per-walker outputs of this range.  Walker i always gets RNG state i and
@@ -288,8 +302,10 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         print("Number of steps = %s" % n_t)
         print("Step length = %s m" % step_l)
         print("Step duration = %s s" % dt)
+    if devices is not None and len(devices) >= 1:
+        device = int(devices[0])
     positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b), dist=dist)
-    with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a) as sim:
+    with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a, devices=devices) as sim:
         sim.rng_init_device(seed)
         if positions is not None:
             sim.set_positions(np.ascontiguousarray(positions, dtype=np.float64))
@@ -398,8 +414,9 @@ def simulation(
         if traj:
             print("The trajectories file will be up to %s GB" % (gradient.shape[1] * n_walkers * 3 * 25 / 1e9))
     np.random.seed(seed)  # the reference seeds the global NumPy generator too (:1169)
+    # the reference runs on one GPU (:1051); here the walkers are spread over every visible GPU behind one handle
     res = _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon,
-                    need_phases=bool(all_signals), need_positions=bool(final_pos))
+                    need_phases=bool(all_signals), need_positions=bool(final_pos), devices=_default_devices(n_gpu))
     iter_exc = res["iter_exc"]
     if np.any(iter_exc):
         warnings.warn(

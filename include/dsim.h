@@ -95,6 +95,21 @@ int dsim_rng_init_device(dsim_handle h, uint64_t seed);
 int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int64_t first_walker, int32_t M, int32_t T,
                 const double *gx, const double *gy, const double *gz, double dt, double step_l);
 
+/* The same simulation spread over several devices of this node behind ONE handle (the reference's
+ * simulation() is one function on one GPU, simulations.py:1051): the walkers [first_walker, first_walker + n_walkers)
+ * are cut into n_devices balanced contiguous ranges (the first n_walkers % n_devices ranges hold one walker more),
+ * range k lives on device device_ids[k] (a device may be named more than once: several shards on one GPU).  Every
+ * other entry point of this header takes the handle as it takes a dsim_create handle: host arrays cover all
+ * n_walkers walkers in order (each shard reads / fills its slice), dsim_run_* advance the shards concurrently (one
+ * host thread per shard), dsim_get_signal adds the shards' sums on the host in shard order, dsim_write_traj writes
+ * lines that hold every walker.  Walker i uses RNG state i and initial position i whatever the split, so per-walker
+ * outputs are identical to a single-device run bit for bit and the signal differs by summation order only.  No
+ * torch, no process group: one process drives all devices. */
+int dsim_create_multi(dsim_handle *out, const int32_t *device_ids, int32_t n_devices, int64_t n_walkers, int64_t first_walker,
+                      int32_t M, int32_t T, const double *gx, const double *gy, const double *gz, double dt, double step_l);
+/* number of shards behind a handle (1 for a dsim_create handle) */
+int dsim_shard_count(dsim_handle h);
+
 int dsim_destroy(dsim_handle h);
 
 /* Initial positions, (n_walkers,3) row-major (cuda.to_device(positions), e.g. :1195). */

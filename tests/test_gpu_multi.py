@@ -1,0 +1,130 @@
+"""Several GPUs behind the ONE drop-in call (``-m gpu``): ``simulations.simulation`` spreads its walkers over every
+visible device through a multi-device handle of the C ABI (include/dsim.h, dsim_create_multi) - no ranks, no torch.
+On the driver's one-GPU box the device list names device 0 twice (two or three shards on the one GPU, DSIM_DEVICES):
+every per-walker output must be the single-shard run's bytes (walker i <- RNG state i and initial position i whatever
+the split; reference outputs: disimpy/simulations.py:1406-1429), the signal its sum in another order."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D = 2e-9
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from disimpy_amd import _lib, gradients, simulations, substrates
+
+    if _lib.device_count() <= 0:
+        pytest.skip("needs an AMD GPU")
+    return _lib, gradients, simulations, substrates
+
+
+def _cases(gradients, substrates):
+    g3, dt3 = gradients.pgse(10e-3, 40e-3, 150, np.array([1e9, 2e9, 5e8]), np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]))
+    yield "free", 10007, g3, dt3, substrates.free(), {}
+    yield "sphere, iteration limit hit", 5003, g3, dt3, substrates.sphere(2e-6), {"max_iter": 1}
+    yield "cylinder", 4099, g3, dt3, substrates.cylinder(3e-6, np.array([1.0, 2.0, 0.5])), {}
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="intra", n_sv=np.array([6, 6, 6]), quiet=True)
+    yield "mesh, walkers placed by the device fill", 9001, g3, dt3, sub, {}
+    g40, dt40 = gradients.pgse(10e-3, 40e-3, 120, np.linspace(1e8, 3e9, 40), np.tile(np.array([[1.0, 0, 0]]), (40, 1)))
+    yield "mesh, 40 measurements", 6000, g40, dt40, sub, {}
+
+
+def _run(simulations, devices, n, gradient, dt, sub, kw, **out):
+    os.environ["DSIM_DEVICES"] = devices
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            res = simulations.simulation(n, D, gradient, dt, sub, seed=321, quiet=True, **kw, **out)
+        return res, [str(x.message) for x in w]
+    finally:
+        del os.environ["DSIM_DEVICES"]
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_shards_on_one_gpu_return_the_single_shard_outputs(mods, devices):
+    _lib, gradients, simulations, substrates = mods
+    for name, n, gradient, dt, sub, kw in _cases(gradients, substrates):
+        (sig1, pos1), w1 = _run(simulations, "0", n, gradient, dt, sub, kw, final_pos=True)
+        (sig2, pos2), w2 = _run(simulations, devices, n, gradient, dt, sub, kw, final_pos=True)
+        assert pos1.tobytes() == pos2.tobytes(), name
+        np.testing.assert_allclose(sig2, sig1, rtol=0, atol=1e-12 * n, err_msg=name)  # summation order only
+        assert w1 == w2, name  # the warning text names the same global walker indices
+        if "iteration" in name:
+            assert len(w1) == 1 and "walkers [" in w1[0]
+        all1, _ = _run(simulations, "0", n, gradient, dt, sub, kw, all_signals=True)
+        all2, _ = _run(simulations, devices, n, gradient, dt, sub, kw, all_signals=True)
+        assert all1.shape == (gradient.shape[0], n) and all1.tobytes() == all2.tobytes(), name
+
+
+def test_trajectories_file_of_a_multi_shard_run_is_the_same_file(mods, tmp_path):
+    _lib, gradients, simulations, substrates = mods
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 40, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    n = 1003
+    files = []
+    for devices in ("0", "0,0,0"):
+        path = str(tmp_path / ("traj_%d.txt" % len(files)))
+        _run(simulations, devices, n, gradient, dt, substrates.sphere(3e-6), {}, traj=path)
+        files.append(open(path, "rb").read())
+    assert len(files[0].splitlines()) == 41 and files[0] == files[1]
+
+
+def test_multi_device_handle_state_round_trips(mods):
+    """the handle's host arrays cover all walkers in order: every shard reads / fills its slice (ragged split, more
+    shards than walkers)"""
+    _lib, gradients, simulations, substrates = mods
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 30, np.array([1e9, 3e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    step_l = float(np.sqrt(6 * D * dt))
+    for n, devices in ((11, [0, 0, 0]), (2, [0, 0, 0, 0]), (4097, [0, 0])):
+        rng = np.random.RandomState(n)
+        pos = rng.standard_normal((n, 3)) * 1e-6
+        with _lib.Sim(n, gradient, dt, step_l, first_walker=5, devices=devices) as multi, \
+                _lib.Sim(n, gradient, dt, step_l, first_walker=5) as one:
+            assert multi.shard_count() == min(n, len(devices)) and one.shard_count() == 1
+            for sim in (multi, one):
+                sim.rng_init_device(99)
+                sim.set_positions(pos)
+            np.testing.assert_array_equal(multi.positions(), pos)
+            np.testing.assert_array_equal(multi.rng_states(), one.rng_states())
+            st = one.rng_states()[::-1].copy()
+            multi.set_rng_states(st)
+            one.set_rng_states(st)
+            for sim in (multi, one):
+                sim.set_recording(True)
+                sim.run_sphere(4e-6, 1000, 1e-13, 0, 30)
+            np.testing.assert_array_equal(multi.positions(), one.positions())
+            np.testing.assert_array_equal(multi.phases(), one.phases())
+            np.testing.assert_array_equal(multi.rng_states(), one.rng_states())
+            np.testing.assert_array_equal(multi.iter_exc(), one.iter_exc())
+            np.testing.assert_array_equal(multi.all_signals(), one.all_signals())
+            np.testing.assert_array_equal(multi.recorded(3, 17), one.recorded(3, 17))
+            c2, s2, e2 = multi.signal()
+            c1, s1, e1 = one.signal()
+            np.testing.assert_allclose(c2, c1, rtol=0, atol=1e-12 * n)
+            np.testing.assert_allclose(s2, s1, rtol=0, atol=1e-12 * n)
+            assert e1 == e2
+    with pytest.raises(_lib.DsimError, match="shard 1 .device 7"):
+        _lib.Sim(10, gradient, dt, step_l, devices=[0, 7])
+
+
+def test_every_visible_gpu_is_used_by_default(mods):
+    """a node with several GPUs: simulation() without DSIM_DEVICES = one shard per visible device"""
+    _lib, gradients, simulations, substrates = mods
+    if _lib.device_count() < 2:
+        pytest.skip("one visible GPU: the default device list is [0] (covered by every other test)")
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 100, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    n = 200001
+    assert simulations._default_devices(_lib.device_count()) == list(range(_lib.device_count()))
+    sig, pos = simulations.simulation(n, D, gradient, dt, substrates.sphere(5e-6), seed=5, quiet=True, final_pos=True)
+    (sig1, pos1), _ = _run(simulations, "0", n, gradient, dt, substrates.sphere(5e-6), {}, final_pos=True)
+    assert pos.tobytes() == pos1.tobytes()
+    np.testing.assert_allclose(sig, sig1, rtol=0, atol=1e-12 * n)

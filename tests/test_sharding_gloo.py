@@ -199,3 +199,123 @@ def test_sharded_fill_reproduces_the_single_process_sequence(world, n, p):
         assert pr.exitcode == 0
     for rank, (a, b), rows in got:
         np.testing.assert_array_equal(rows, want[a:b])
+
+
+class _OverflowingFill(_FakeFill):
+    """a session whose buffer is too small on ONE rank: more points accepted than fit `capacity` while more are needed"""
+
+    def run(self, n_launches, capacity):
+        counts, pts = super().run(n_launches, capacity)
+        return counts, pts[: max(0, min(len(pts), 3))]
+
+
+def _worker_fill_fails(rank, world, port, n, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disimpy_amd import sharding
+
+    class _Raising(_FakeFill):
+        def run(self, n_launches, capacity):
+            raise RuntimeError("device lost")
+
+    def open_session(t0, t1):
+        if rank == 1:
+            return _OverflowingFill(t0, t1, 0.5) if mode == "overflow" else _Raising(t0, t1, 0.5)
+        return _FakeFill(t0, t1, 0.5)
+
+    try:
+        sharding.fill_mesh_sharded(n, open_session, dist)
+        q.put((rank, "returned"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()  # every rank is still alive and in step: nobody was left behind in a collective
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["overflow", "raises"])
+def test_a_failing_rank_ends_the_sharded_fill_on_every_rank(mode):
+    """the overflow error was raised on one rank only, before the all-gather - the others hung in it"""
+    world, n = 2, 4000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fill_fails, args=(r, world, port, n, mode, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all("rank 1 failed" in msg for msg in got.values()), got
+    assert ("overflow" in got[1]) if mode == "overflow" else ("device lost" in got[1])
+
+
+def _oracle_simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon, device=0,
+                     walker_range=None, need_phases=False, need_positions=False, dist=None, devices=None):
+    """stand-in for simulations._simulate with the CPU oracle as the engine (sphere; walker i <- state i, position i)"""
+    from disimpy_amd import simulations
+    from oracle.oracle import SPHERE, Oracle
+
+    a, b = walker_range
+    o = Oracle(exact=True)
+    step_l = float(np.sqrt(6 * diffusivity * dt))
+    pos = np.ascontiguousarray(simulations._fill_sphere(b, substrate.radius, simulations._host_rng(seed))[a:b])
+    st = o.rng_states(b, seed)[a:].copy()
+    ph, exc, _ = o.run(o.geom(SPHERE, radius=substrate.radius, max_iter=max_iter, epsilon=epsilon), gradient, dt, step_l, pos, st)
+    c, s = o.signal(ph, exc)
+    sig = np.cos(ph)
+    sig[:, exc.astype(bool)] = np.nan
+    return {"cos": c, "sin": s, "n_exceeded": int(exc.sum()), "iter_exc": exc.astype(bool), "all_signals": sig, "positions": pos}
+
+
+def _worker_outputs(rank, world, port, n, max_iter, q):
+    import warnings
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disimpy_amd import gradients, sharding, simulations, substrates
+
+    simulations._simulate = _oracle_simulate
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 40, np.array([1e9, 5e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sig, pos = sharding.simulation_sharded(n, 2e-9, gradient, dt, substrates.sphere(2e-6), seed=7, dist=dist, max_iter=max_iter,
+                                               final_pos=True, all_signals=True)
+        total = sharding.simulation_sharded(n, 2e-9, gradient, dt, substrates.sphere(2e-6), seed=7, dist=dist, max_iter=max_iter)
+    q.put((rank, sig, pos, total, [str(x.message) for x in w]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,max_iter", [(2, 301, 1000), (3, 100, 1)])
+def test_sharded_simulation_returns_every_per_walker_output(world, n, max_iter):
+    """final_pos, all_signals and the iteration-limit warning of simulation() (disimpy/simulations.py:1406-1429) from a
+    job of one process per GPU: per-walker outputs gathered in walker order, the warning with global indices"""
+    from disimpy_amd import gradients, substrates
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_outputs, args=(r, world, port, n, max_iter, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 40, np.array([1e9, 5e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    one = _oracle_simulate(n, 2e-9, gradient, dt, substrates.sphere(2e-6), 7, None, True, max_iter, 1e-13, walker_range=(0, n))
+    for rank, sig, pos, total, warned in got:
+        np.testing.assert_array_equal(sig, one["all_signals"])
+        np.testing.assert_array_equal(pos, one["positions"])
+        np.testing.assert_allclose(total, one["cos"], rtol=0, atol=1e-12 * n)
+        if one["n_exceeded"]:
+            want = "check algorithm for walkers %s" % np.where(one["iter_exc"])[0]
+            assert len(warned) == 2 and all(want in m for m in warned), warned
+        else:
+            assert not warned
+    assert max_iter > 1 or one["n_exceeded"] > 0  # the max_iter = 1 case does exercise the warning
