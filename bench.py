@@ -277,6 +277,40 @@ def signal_rel_err(w, positions, device, n=2048):
     return out
 
 
+def snapshot_sample(sim, idx):
+    """Per-walker state of the walkers `idx` of the shard as it stands (positions, phases, RNG states, iter_exc)."""
+    return dict(pos=sim.positions()[idx], ph=sim.phases()[:, idx], st=sim.rng_states()[idx], exc=np.asarray(sim.iter_exc())[idx])
+
+
+def check_sample_of_timed_run(w, positions, first_walker, idx, snap):
+    """The run bench.py TIMES, pinned: `snap` holds 512 walkers spread over rank 0's shard as the first (warm-up) pass
+    over the waveform left them - the pass that starts from the initial state, after which the timed passes continue the
+    same walk.  The exact build of the CPU oracle runs those walkers alone from the same initial positions and RNG
+    states over all T steps (walkers are independent, so the sample pins the full-size run with everything it goes
+    through: walker groups, spatial sorts, per-walker clocks, restored order); bit-identity of positions, phases, RNG
+    states and iter_exc is reported as "identical"."""
+    from disimpy_amd import _lib
+    from oracle.oracle import STATE_DTYPE, Oracle
+
+    o = Oracle(exact=True)
+    sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
+    step_l = float(np.sqrt(6 * w["D"] * dt))
+    T = gradient.shape[1]
+    st0 = np.concatenate([_lib.rng_init(123, int(first_walker + i), 1) for i in idx])
+    st = np.zeros(len(idx), dtype=STATE_DTYPE)
+    st["s0"], st["s1"] = st0[:, 0], st0[:, 1]
+    pos = np.zeros((len(idx), 3)) if sub.type == "free" else np.ascontiguousarray(positions[idx], dtype=np.float64)
+    t0 = time.perf_counter()
+    ph, exc, _ = o.run(oracle_geometry(o, sub), gradient, dt, step_l, pos, st, n_threads=os.cpu_count() or 1)
+    same = {"positions": bool(np.array_equal(pos, snap["pos"])), "phases": bool(np.array_equal(ph, snap["ph"])),
+            "rng_states": bool(np.array_equal(np.stack([st["s0"], st["s1"]], axis=1), snap["st"])),
+            "iter_exc": bool(np.array_equal(exc.astype(bool), snap["exc"].astype(bool)))}
+    return {"walkers": int(len(idx)), "steps": int(T), "of": "the first pass of this run (warm-up, from the initial state; the timed "
+            "passes continue it)", "result": "identical" if all(same.values()) else "DIFFERENT", "fields": same,
+            "max_abs_position_difference_m": float(np.max(np.abs(pos - snap["pos"]))) if len(idx) else 0.0,
+            "oracle_s": time.perf_counter() - t0}
+
+
 def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
     """n_steps passes over the waveform; returns (elapsed s, walk-kernel ms per step, launches, last signal)."""
     from disimpy_amd import sharding, simulations
@@ -512,9 +546,16 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    first_pass = None
+    first_pass, timed_sample = None, None
     if args.warmup:
-        _, _, _, _, first_pass = run_steps(sim, sub, frames, T, args.warmup, dist, device, fence, M)
+        _, _, _, _, first_pass = run_steps(sim, sub, frames, T, 1, dist, device, fence, M)
+        if rank == 0 and sim is not None and not args.no_signal_check:
+            # 512 walkers from all over the shard as the pass from the initial state left them: compared with the CPU
+            # oracle after the timed region (check_sample_of_timed_run)
+            idx = np.unique(np.linspace(0, n_local - 1, 512).astype(np.int64))
+            timed_sample = (idx, snapshot_sample(sim, idx))
+        if args.warmup > 1:
+            run_steps(sim, sub, frames, T, args.warmup - 1, dist, device, fence, M)
     elapsed, walk_ms, run_ms, launches, sig = run_steps(sim, sub, frames, T, args.steps, dist, device, fence, M)
     if first_pass is None:
         first_pass = sig
@@ -583,7 +624,7 @@ def main(argv=None):
                  "issue_unit": "wave-instr/s at 4 cycles per wave64 instruction"},
         "note": "register-resident fused kernel: bound by vector-ALU time and dependent index look-ups, not by "
                 "HBM.  Deviations from the north star's sketch, measured and kept: the mesh kernel reads triangle "
-                "records through L1/L2 (7 MB index, Morton-sorted walkers) instead of staging lists in LDS, and "
+                "records through L1/L2 (an index of tens of MB - the fine grid of overlapping cells - read by Morton-sorted walkers) instead of staging lists in LDS, and "
                 "with M <= 4 it reads the gradient samples from global memory (32 B per measurement and step out of L1) instead "
                 "of an LDS tile; LDS holds the log/cos tables, the subvoxel boundaries and the wave work queues.",
     }
@@ -610,6 +651,9 @@ def main(argv=None):
         positions = np.zeros((1, 3))
     if rank == 0 and not args.no_signal_check:
         out["signal_rel_err"] = signal_rel_err(w, positions, device)
+        out["signal_rel_err"]["sample_of_timed_run"] = (
+            check_sample_of_timed_run(w, positions, a, *timed_sample) if timed_sample is not None else
+            "not taken (needs --warmup >= 1: the first pass starts from the initial state)")
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(w, positions)
     if rank == 0 and not args.no_secondary and world == 1:

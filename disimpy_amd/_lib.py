@@ -49,13 +49,22 @@ def load():
         )
     lib = C.CDLL(LIB_PATH)
     missing = [name for name in SYMBOLS if not hasattr(lib, name)]
-    if missing:  # also for a build named by DSIM_LIB (A/B timing runs): a library that lacks a declared symbol is not loaded
+    if missing and not (os.environ.get("DSIM_LIB") and os.environ.get("DSIM_LIB_OLD_ABI")):
+        # also for a build named by DSIM_LIB (A/B timing runs): a library that lacks a declared symbol is not loaded -
+        # unless DSIM_LIB_OLD_ABI says that it is an OLDER build kept for a same-box comparison (tools/gpu_ab.sh), whose
+        # missing entry points the run does not use
         raise DsimError("%s lacks %s: rebuild it (make -C disimpy_amd/csrc)" % (LIB_PATH, ", ".join(missing)))
     lib.dsim_last_error.restype = C.c_char_p
     lib.dsim_rng_init.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
     lib.dsim_rng_init_device.argtypes = [_h, C.c_uint64]
     lib.dsim_create.argtypes = [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _f64p, _f64p,
                                 _f64p, C.c_double, C.c_double]
+    if missing:  # DSIM_LIB_OLD_ABI: the calls below that name a missing symbol are skipped
+        class _Absent:
+            argtypes = restype = None
+
+        for name in missing:
+            setattr(lib, name, _Absent())
     lib.dsim_create_multi.argtypes = [C.POINTER(_h), _i32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _f64p, _f64p,
                                       _f64p, C.c_double, C.c_double]
     lib.dsim_shard_count.argtypes = [_h]

@@ -262,6 +262,23 @@ struct BestHit {
   int tri;
 };
 
+/* The launch parameters, read afresh.  A kernel argument struct of ~100 dwords that is read through its by-value
+ * parameter is fetched into SGPRs once and kept there for the whole kernel; the cooperative mesh kernel, whose pass
+ * loop needs most of the scalar file for itself, then spills them through VGPR lanes (v_writelane / v_readlane are
+ * VALU instructions in a VALU-bound kernel: round 2 shipped with 124 spilled SGPRs).  With KA = 1 the kernel instead
+ * re-reads what a stage needs from the kernarg segment (scalar loads out of the constant cache) through a pointer the
+ * compiler cannot see through, so no value lives longer than the stage that uses it.  KA = 0 (every other kernel, and
+ * the test wrappers): the by-value parameter as it is.  WalkParams must be the kernel's first and only argument. */
+template <int KA>
+DSD const WalkParams &fresh_params(const WalkParams &p) {
+  if (KA) {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const WalkParams *)k;
+  }
+  return p;
+}
+
 /* One iteration of the reflect loop exactly as the reference does it (simulations.py:936-983): every triangle of
  * every subvoxel in range, in the reference's order, no culling, the first smallest distance wins.  The fall-back
  * of both traversals - for a walker whose work does not fit the wavefront's queues, and whenever two different
@@ -359,15 +376,19 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
 }
 
 /* simulations.py:878-1002.  xs/ys/zs: LDS copies of the subvoxel boundaries. */
-DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const double *xs, const double *ys,
+template <int KA>
+DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p_arg, const double *xs, const double *ys,
                    const double *zs, Rng &rng, bool &exc) {
-  const MeshDev &ms = p.mesh;
-  const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
-  const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
   int64_t iter_idx = 0;
   bool check = true;
   int closest = 0;
-  while (check && step_l > 0 && iter_idx < p.max_iter) {
+  while (check && step_l > 0 && iter_idx < fresh_params<KA>(p_arg).max_iter) {
+    /* KA = 1: the launch parameters are re-read per pass (and once more per subvoxel below): none of the ~40 dwords of
+     * MeshDev occupies an SGPR for the whole kernel */
+    const WalkParams &p = fresh_params<KA>(p_arg);
+    const MeshDev &ms = p.mesh;
+    const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+    const double Lx = xs[nx], Ly = ys[ny], Lz = zs[nz];
     iter_idx++;
     STAT_LANE(0);
     STAT_WAVE(0);
@@ -382,67 +403,71 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
     int ulx = ul_subvoxel_overlap_periodic(xs, nx, ms.inv_hx, ms.inv_lx, r0.x, ex);
     int uly = ul_subvoxel_overlap_periodic(ys, ny, ms.inv_hy, ms.inv_ly, r0.y, ey);
     int ulz = ul_subvoxel_overlap_periodic(zs, nz, ms.inv_hz, ms.inv_lz, r0.z, ez);
-    for (int xi = llx; xi < ulx; xi++) {
-      int x = xi;
-      double shx = 0;
+    /* the subvoxels of the range in the reference's order (x outermost, z innermost) as ONE loop with a carrying
+     * counter, the columns of cells of a subvoxel likewise: every level of nested divergent loops costs a saved
+     * execution mask in the scalar registers, and eight levels of them spilled */
+    const bool some = ulx > llx && uly > lly && ulz > llz;
+    for (int xi = llx, yi = lly, zi = llz; some && xi < ulx;) {
+      const MeshDev &ms = fresh_params<KA>(p_arg).mesh;
+      const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
+      int x = xi, y = yi, z = zi;
+      double shx = 0, shy = 0, shz = 0;
       if (x < 0 || x > nx - 1) {
         int sn = floor_div(x, nx);
         x -= sn * nx;
         shx = (double)sn * Lx;
       }
-      for (int yi = lly; yi < uly; yi++) {
-        int y = yi;
-        double shy = 0;
-        if (y < 0 || y > ny - 1) {
-          int sn = floor_div(y, ny);
-          y -= sn * ny;
-          shy = (double)sn * Ly;
-        }
-        for (int zi = llz; zi < ulz; zi++) {
-          int z = zi;
-          double shz = 0;
-          if (z < 0 || z > nz - 1) {
-            int sn = floor_div(z, nz);
-            z -= sn * nz;
-            shz = (double)sn * Lz;
-          }
-          const int sv = (x * ny + y) * nz + z;
-          STAT_LANE(1);
-          STAT_WAVE(1);
-          const int lk = ms.lk;
-          int base = sv;
-          if (lk > 0) {
-            base = ms.sv_base[sv];
-            if (base < 0) continue; /* empty subvoxel */
-          }
-          STAT_LANE(2);
-          STAT_WAVE(2);
-          V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
-          const CullBox cb = make_cull_box(tr0, step, step_l);
-          if (lk == 0) {
+      if (y < 0 || y > ny - 1) {
+        int sn = floor_div(y, ny);
+        y -= sn * ny;
+        shy = (double)sn * Ly;
+      }
+      if (z < 0 || z > nz - 1) {
+        int sn = floor_div(z, nz);
+        z -= sn * nz;
+        shz = (double)sn * Lz;
+      }
+      const int sv = (x * ny + y) * nz + z;
+      STAT_LANE(1);
+      STAT_WAVE(1);
+      const int lk = ms.lk;
+      int base = sv;
+      if (lk > 0) base = ms.sv_base[sv];
+      if (base >= 0) { /* not an empty subvoxel */
+        STAT_LANE(2);
+        STAT_WAVE(2);
+        V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
+        const CullBox cb = make_cull_box(tr0, step, step_l);
+        if (lk == 0) {
+          STAT_LANE(3);
+          STAT_WAVE(3);
+          scan_candidates(ms, (int)ms.cell_start[base], (int)ms.cell_start[base + 1], cb, tr0, step, min_d, closest, tie);
+        } else {
+          /* x, y: 2k half-cell units per subvoxel, a cell of two units at every unit but the last (dsim_mesh_host.h):
+           * the units u0 .. u1 of the box are covered by the cells at u0, u0 + 2, ... */
+          const int k = 1 << lk, k2 = 2 * k;
+          const double sx = (double)k2 * ms.inv_hx, sy = (double)k2 * ms.inv_hy, sz = (double)k * ms.inv_hz;
+          const int a0 = micro_cell((double)cb.lox, xs[x], sx, k2), a1 = micro_cell((double)cb.hix, xs[x], sx, k2);
+          const int b0 = micro_cell((double)cb.loy, ys[y], sy, k2), b1 = micro_cell((double)cb.hiy, ys[y], sy, k2);
+          const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
+          for (int a = a0, b = b0;;) {
             STAT_LANE(3);
             STAT_WAVE(3);
-            scan_candidates(ms, (int)ms.cell_start[base], (int)ms.cell_start[base + 1], cb, tr0, step, min_d, closest, tie);
-          } else {
-            /* x, y: 2k half-cell units per subvoxel, a cell of two units at every unit but the last (dsim_mesh_host.h):
-             * the units u0 .. u1 of the box are covered by the cells at u0, u0 + 2, ... */
-            const int k = 1 << lk, k2 = 2 * k;
-            const double sx = (double)k2 * ms.inv_hx, sy = (double)k2 * ms.inv_hy, sz = (double)k * ms.inv_hz;
-            const int a0 = micro_cell((double)cb.lox, xs[x], sx, k2), a1 = micro_cell((double)cb.hix, xs[x], sx, k2);
-            const int b0 = micro_cell((double)cb.loy, ys[y], sy, k2), b1 = micro_cell((double)cb.hiy, ys[y], sy, k2);
-            const int c0 = micro_cell((double)cb.loz, zs[z], sz, k), c1 = micro_cell((double)cb.hiz, zs[z], sz, k);
-            for (int a = a0;; a += 2) {
-              for (int b = b0;; b += 2) {
-                STAT_LANE(3);
-                STAT_WAVE(3);
-                const int c = base + (min(a, k2 - 2) * k2 + min(b, k2 - 2)) * k; /* the cells c0 .. c1 of this column: one run of records */
-                scan_candidates(ms, (int)ms.cell_start[c + c0], (int)ms.cell_start[c + c1 + 1], cb, tr0, step, min_d, closest, tie);
-                if (b + 1 >= b1) break;
-              }
-              if (a + 1 >= a1) break;
+            const int c = base + (min(a, k2 - 2) * k2 + min(b, k2 - 2)) * k; /* the cells c0 .. c1 of this column: one run of records */
+            scan_candidates(ms, (int)ms.cell_start[c + c0], (int)ms.cell_start[c + c1 + 1], cb, tr0, step, min_d, closest, tie);
+            if (b + 1 < b1) {
+              b += 2;
+            } else if (a + 1 < a1) {
+              a += 2, b = b0;
+            } else {
+              break;
             }
           }
         }
+      }
+      if (++zi == ulz) {
+        zi = llz;
+        if (++yi == uly) yi = lly, xi++;
       }
     }
     if (tie && min_d <= step_l) {
@@ -469,27 +494,10 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p, const d
       step_l -= min_d;
     }
   }
-  if (iter_idx >= p.max_iter) exc = true;
+  if (iter_idx >= fresh_params<KA>(p_arg).max_iter) exc = true;
   r0.x = __builtin_fma(step.x, step_l, r0.x);
   r0.y = __builtin_fma(step.y, step_l, r0.y);
   r0.z = __builtin_fma(step.z, step_l, r0.z);
-}
-
-/* The launch parameters, read afresh.  A kernel argument struct of ~100 dwords that is read through its by-value
- * parameter is fetched into SGPRs once and kept there for the whole kernel; the cooperative mesh kernel, whose pass
- * loop needs most of the scalar file for itself, then spills them through VGPR lanes (v_writelane / v_readlane are
- * VALU instructions in a VALU-bound kernel: round 2 shipped with 124 spilled SGPRs).  With KA = 1 the kernel instead
- * re-reads what a stage needs from the kernarg segment (scalar loads out of the constant cache) through a pointer the
- * compiler cannot see through, so no value lives longer than the stage that uses it.  KA = 0 (every other kernel, and
- * the test wrappers): the by-value parameter as it is.  WalkParams must be the kernel's first and only argument. */
-template <int KA>
-DSD const WalkParams &fresh_params(const WalkParams &p) {
-  if (KA) {
-    auto k = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    return *(const WalkParams *)k;
-  }
-  return p;
 }
 
 #include "dsim_mesh_coop.h"
@@ -659,6 +667,7 @@ DSD void walk_body(const WalkParams &p_arg) {
 #endif
     } else if (live) {
       for (int k = 0; k < kt; k++) {
+        const WalkParams &p = fresh_params<KA>(p_arg); /* mesh (KA = 1): no launch parameter stays in SGPRs across time steps */
         V3 step = random_step(rng, log_tab, cos_tab);
         if (GEOM == GEOM_FREE) {
           /* simulations.py:690-691 */
@@ -672,7 +681,7 @@ DSD void walk_body(const WalkParams &p_arg) {
         } else if (GEOM == GEOM_ELLIPSOID) {
           step_ellipsoid(r, step, p.step_l, p, exc);
         } else {
-          step_mesh(r, step, p.step_l, p, xs, ys, zs, rng, exc);
+          step_mesh<KA>(r, step, p.step_l, p_arg, xs, ys, zs, rng, exc);
         }
         if (TRAJ) {
           double *q = p.traj + (int64_t)(t0 + k - p.t_begin) * 3 * p.n + i;
@@ -721,7 +730,10 @@ DSD void walk_body(const WalkParams &p_arg) {
 
 template <int GEOM, int MB, int GSRC, int COOP>
 __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
-  walk_body<GEOM, MB, GSRC, COOP>(p);
+  /* the mesh kernels (per-lane traversal, and the cooperative one with more than four accumulators) re-read their launch
+   * parameters where they use them (fresh_params): read once, MeshDev alone is ~40 SGPRs that the traversal's loops
+   * then spill through VGPR lanes */
+  walk_body<GEOM, MB, GSRC, COOP, 0, GEOM == GEOM_MESH ? 1 : 0>(p);
 }
 
 /* Cooperative mesh traversal with few phase accumulators: capped at 128 VGPRs (a handful of
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
  * of replaying the walk */
 template <int GEOM>
 __global__ __launch_bounds__(256) void walk_kernel_traj32(const WalkParams p) {
-  walk_body<GEOM, 32, 0, 0, 1>(p);
+  walk_body<GEOM, 32, 0, 0, 1, GEOM == GEOM_MESH ? 1 : 0>(p);
 }
 
 /* the same, recording the position after every step in p.traj (phases are then accumulated by

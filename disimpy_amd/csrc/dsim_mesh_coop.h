@@ -561,13 +561,14 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           cursor += 1;
           continue;
         }
-        if (lane < n_take) {
-          const int base = n_items + incl - nb;
+        if (lane < n_take && nb > 0) {
+          /* items of four records; the last one holds what is left (its count goes in after the loop: the loop itself is
+           * one store and two additions per item - its trip count is the longest run of the 64) */
           const unsigned tag = e.x & 0xffffffu;
-          for (int j = 0; j < nb; j++) {
-            const int left = cnt - 4 * j;
-            W->items[base + j] = make_uint2((unsigned)(first + 4 * j) | ((unsigned)((left < 4 ? left : 4) - 1) << 30), tag);
-          }
+          uint2 *q = &W->items[n_items + incl - nb];
+          unsigned x = (unsigned)first | (3u << 30);
+          for (uint2 *const end = q + nb - 1; q < end; q++, x += 4u) *q = make_uint2(x, tag);
+          *q = make_uint2((x & 0x3fffffffu) | ((unsigned)(cnt - 4 * (nb - 1) - 1) << 30), tag);
         }
         n_items += __builtin_amdgcn_readlane(incl, n_take - 1);
         cursor += n_take;

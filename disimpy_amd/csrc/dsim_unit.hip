@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void mesh_pass_kernel(const WalkParams p, cons
   int flags = 0;
   if (a.mode == 1) {
     bool exc = false;
-    if (live) step_mesh(r, step, sl, p, xs, ys, zs, rng, exc);
+    if (live) step_mesh<0>(r, step, sl, p, xs, ys, zs, rng, exc);
     flags = 1 | (exc ? 2 : 0);
     sl = DS_NAN; /* step_mesh keeps the remaining length to itself */
   } else {

@@ -213,13 +213,16 @@ int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertices, const in
                             double step_l, int32_t *clear_idx, uint32_t *clear_bits, int64_t *n_words,
                             int32_t *log2_cells);
 
-/* Host only: the fine grid dsim_set_mesh builds on top of the reference's subvoxel lists - every non-empty
- * subvoxel cut into k^3 cells, k = 1 << *log2_cells; the records of cell c are [cell_start[c], cell_start[c + 1]),
- * subvoxel s owns the cells sv_base[s] .. sv_base[s] + k^3 - 1 in z-fastest order (sv_base[s] = -1: empty; *log2_cells
- * == 0: cells are the subvoxels themselves and sv_base is not written).  Per record the triangle, its position in the
- * reference's triangle_indices and the float32 box {min x, y, z, max x, y, z} of the triangle's part inside the cell.
- * Exported so that the completeness of the grid can be tested without a GPU (tests/test_fine_grid.py).  Call once with
- * cell_start == NULL for the sizes, then with buffers of *n_cells + 1 and *n_records elements. */
+/* Host only: the fine grid dsim_set_mesh builds on top of the reference's subvoxel lists, k = 1 << *log2_cells.
+ * k == 1: the cells are the subvoxels themselves (cell_start has prod(n_sv) + 1 entries, sv_base is not written).
+ * k > 1: along x and y a non-empty subvoxel is cut into 2k units and there is a cell of two units at every unit but the
+ * last (the cells overlap), along z into k cells; the subvoxel owns the slots sv_base[s] .. sv_base[s] + (2k)^2 k - 1
+ * (sv_base[s] = -1: empty), slot ((i * 2k + j) * k + c) = the cell that starts at unit i along x, unit j along y, z cell c
+ * (the slots with i or j = 2k - 1 stay empty).  The records of slot q are [cell_start[q], cell_start[q + 1]).  Per record
+ * the triangle, its position in the reference's triangle_indices and the float32 box {min x, y, z, max x, y, z} of the
+ * triangle's part inside the cell.  Exported so that the completeness of the grid can be tested without a GPU
+ * (tests/test_fine_grid.py).  Call once with cell_start == NULL for the sizes, then with buffers of *n_cells + 1 and
+ * *n_records elements. */
 int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
                         const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
                         const int64_t *triangle_indices, int64_t n_refs, double step_l, int32_t *log2_cells, int64_t *n_cells,

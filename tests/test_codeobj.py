@@ -39,3 +39,15 @@ def test_free_and_analytic_geometry_kernels_use_no_scratch(kernels):
     for geom in range(4):
         for k in _find(kernels, "walk_kernel<%d," % geom):
             assert k.get("private_segment_fixed_size", 0) == 0 and k.get("vgpr_spill_count", 0) == 0, k
+
+
+def test_no_kernel_of_the_library_spills(kernels):
+    """the fall-back kernels (per-lane mesh traversal, the 32-accumulator recording kernel) kept
+    ~100 dwords of launch parameters and eight levels of saved execution masks in SGPRs and spilled 107-187 of them.
+    Every kernel of the code object - not only the headline one - now stays within 16 spilled SGPRs, spills no VGPR and
+    uses no scratch memory."""
+    assert len(kernels) > 50
+    bad = {n: (k.get("sgpr_spill_count", 0), k.get("vgpr_spill_count", 0), k.get("private_segment_fixed_size", 0))
+           for n, k in kernels.items()
+           if k.get("sgpr_spill_count", 0) > 16 or k.get("vgpr_spill_count", 0) > 0 or k.get("private_segment_fixed_size", 0) > 0}
+    assert not bad, bad

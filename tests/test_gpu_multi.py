@@ -112,7 +112,7 @@ def test_multi_device_handle_state_round_trips(mods):
             np.testing.assert_allclose(c2, c1, rtol=0, atol=1e-12 * n)
             np.testing.assert_allclose(s2, s1, rtol=0, atol=1e-12 * n)
             assert e1 == e2
-    with pytest.raises(_lib.DsimError, match="shard 1 .device 7"):
+    with pytest.raises(_lib.DsimError, match="shard 1 on device 7"):
         _lib.Sim(10, gradient, dt, step_l, devices=[0, 7])
 
 
