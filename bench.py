@@ -330,10 +330,15 @@ def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
                 busy, streams = ms, 1
             walk_ms.append((ms, busy, streams))
             launches.append(nl)
-            c, s, nexc = sim.signal()
+            try:
+                limbs, nexc = sim.signal_limbs()  # exact integer sums of the device reduction
+            except (AttributeError, TypeError):  # an older build named by DSIM_LIB + DSIM_LIB_OLD_ABI (same-box A/B): one rank only
+                c, s, nexc = sim.signal()
+                sig = (c, s, nexc)
+                continue
         else:  # a rank without walkers still takes part in the collective
-            c, s, nexc = np.zeros(M), np.zeros(M), 0
-        sig = sharding.reduce_signal(c, s, nexc, dist, device)
+            limbs, nexc = np.zeros(4 * M, dtype=np.int64), 0
+        sig = sharding.reduce_signal_exact(limbs, nexc, dist, device)
     fence()
     return time.perf_counter() - t0, walk_ms, run_ms, launches, sig
 
@@ -635,7 +640,7 @@ def main(argv=None):
         "config": {
             "workload": w["label"], "total_walkers": n_total, "walkers_per_gpu": n_local, "time_steps": T,
             "measurements": M, "substrate": sub.type, "triangles": int(len(sub.faces)) if sub.type == "mesh" else 0,
-            "seed": 123, "sharding": "balanced walker ranges, 1 all-reduce of 2M+1 f64 per step (%s)" % args.backend,
+            "seed": 123, "sharding": "balanced walker ranges, 1 all-reduce of 4M+1 int64 (exact signal sums) per step (%s)" % args.backend,
         },
         "roofline": roofline,
         "walk_kernel_spin_steps_per_s": n_local * T / (walk_ms_step * 1e-3),

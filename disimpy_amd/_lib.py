@@ -20,7 +20,7 @@ SYMBOLS = (
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
     "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close", "dsim_mesh_fine_grid",
-    "dsim_create_multi", "dsim_shard_count",
+    "dsim_create_multi", "dsim_shard_count", "dsim_get_signal_limbs", "dsim_signal_from_limbs",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -79,6 +79,8 @@ def load():
     lib.dsim_run_ellipsoid.argtypes = [_h, _f64p, _f64p, _f64p, C.c_int64, C.c_double, C.c_int32, C.c_int32]
     lib.dsim_run_mesh.argtypes = [_h, C.c_int64, C.c_double, C.c_double, C.c_int32, C.c_int32]
     lib.dsim_get_signal.argtypes = [_h, _f64p, _f64p, _i64p]
+    lib.dsim_get_signal_limbs.argtypes = [_h, _i64p, _i64p]
+    lib.dsim_signal_from_limbs.argtypes = [C.c_int32, _i64p, _f64p, _f64p]
     lib.dsim_get_positions.argtypes = [_h, _f64p]
     lib.dsim_get_phases.argtypes = [_h, _f64p]
     lib.dsim_get_iter_exc.argtypes = [_h, _u8p]
@@ -344,6 +346,13 @@ class Sim:
         check(self._lib.dsim_get_signal(self._h, p_f64(c), p_f64(s), C.byref(nexc)))
         return c, s, nexc.value
 
+    def signal_limbs(self):
+        """(limbs (4 M,) int64, n_exceeded): the exact integer sums behind ``signal()`` - limbs of shards / ranks add"""
+        limbs = np.zeros(4 * self.M, dtype=np.int64)
+        nexc = C.c_int64(0)
+        check(self._lib.dsim_get_signal_limbs(self._h, p_i64(limbs), C.byref(nexc)))
+        return limbs, nexc.value
+
     def positions(self):
         out = np.zeros((self.n, 3))
         check(self._lib.dsim_get_positions(self._h, p_f64(out)))
@@ -369,6 +378,15 @@ class Sim:
         out = np.zeros((self.n, 2), dtype=np.uint64)
         check(self._lib.dsim_get_rng_states(self._h, p_u64(out)))
         return out
+
+
+def signal_from_limbs(limbs):
+    """(cos (M,), sin (M,)) from summed limbs (dsim_signal_from_limbs: exact sum, rounded once; needs no GPU)"""
+    limbs = _c(limbs, np.int64)
+    M = len(limbs) // 4
+    c, s = np.zeros(M), np.zeros(M)
+    check(load().dsim_signal_from_limbs(M, p_i64(limbs), p_f64(c), p_f64(s)))
+    return c, s
 
 
 def write_traj_line(path, positions, append=False):

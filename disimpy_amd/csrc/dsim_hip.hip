@@ -195,7 +195,7 @@ struct dsim_sim {
   double *phase = nullptr;
   uint8_t *exc = nullptr;
   double *g4 = nullptr;
-  double *partial = nullptr, *nexc_partial = nullptr, *sig_out = nullptr;
+  long long *partial = nullptr, *nexc_partial = nullptr, *sig_out = nullptr; /* exact signal sums: integer limbs (dsim_kernels.h) */
   int sig_blocks = 0;
   void *staging = nullptr;
   size_t staging_bytes = 0;
@@ -386,9 +386,9 @@ static int create_impl(dsim_sim *h, const double *gx, const double *gy, const do
   HIP_TRY(hipMalloc(&h->g4, g4.size() * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(h->g4, g4.data(), g4.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   h->sig_blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
-  HIP_TRY(hipMalloc(&h->partial, (size_t)h->M * h->sig_blocks * 2 * sizeof(double)));
-  HIP_TRY(hipMalloc(&h->nexc_partial, (size_t)h->sig_blocks * sizeof(double)));
-  HIP_TRY(hipMalloc(&h->sig_out, (size_t)(2 * h->M + 1) * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->partial, (size_t)h->M * h->sig_blocks * 4 * sizeof(long long)));
+  HIP_TRY(hipMalloc(&h->nexc_partial, (size_t)h->sig_blocks * sizeof(long long)));
+  HIP_TRY(hipMalloc(&h->sig_out, (size_t)(4 * h->M + 1) * sizeof(long long)));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return DSIM_OK;
 }
@@ -618,7 +618,8 @@ extern "C" int dsim_get_all_signals(dsim_handle h, double *signals) {
     const int b = k & 1;
     const int64_t count = std::min(per, total - first);
     double *dev = (double *)h->staging + (size_t)b * per;
-    all_signals_kernel<<<grid_for(count, 256), 256, 0, h->stream>>>(h->phase, h->exc, h->n, first, count, dev);
+    const int64_t row0 = first / h->n, row1 = (first + count - 1) / h->n;
+    all_signals_kernel<<<dim3((unsigned)grid_for(h->n, 256), (unsigned)(row1 - row0 + 1)), 256, 0, h->stream>>>(h->phase, h->exc, h->n, first, count, row0, dev);
     if (hipGetLastError() != hipSuccess) return finish(fail(DSIM_ERR_HIP, "all_signals_kernel launch failed"));
     if (hipEventRecord(done[b], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[b], 0) != hipSuccess ||
         hipMemcpyAsync(h->pin[b], dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess ||
@@ -647,42 +648,60 @@ extern "C" int dsim_get_iter_exc(dsim_handle h, uint8_t *exc) {
   return DSIM_OK;
 }
 
-extern "C" int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_exceeded) {
+/* exact sum q * 2^-60 of a signal from its limbs (dsim_kernels.h), rounded once to double */
+static double signal_from_limbs(int64_t hi, int64_t lo) {
+  const __int128 q = ((__int128)hi << DS_SIG_LIMB_BITS) + (__int128)lo;
+  return (double)q * (1.0 / DS_SIG_SCALE); /* int128 -> double is correctly rounded, the power of two exact */
+}
+
+extern "C" int dsim_get_signal_limbs(dsim_handle h, int64_t *limbs, int64_t *n_exceeded) {
+  if (!h || !limbs) return fail(DSIM_ERR_INVALID, "dsim_get_signal_limbs: null argument");
   if (IS_MULTI(h)) {
-    /* the shards' sums added up on the host in shard order (deterministic for a given device list) */
-    if (!out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
-    const size_t G = h->shards.size(), M = (size_t)h->M;
-    std::vector<double> c(G * M), sn(G * M);
+    /* integer sums: the shards' limbs simply add */
+    const size_t G = h->shards.size(), L = (size_t)4 * (size_t)h->M;
+    std::vector<int64_t> part(G * L);
     std::vector<int64_t> ne(G, 0);
-    const int rc = multi_each(h, [&](int k, dsim_sim *sh, int64_t) -> int { return dsim_get_signal(sh, &c[(size_t)k * M], &sn[(size_t)k * M], &ne[(size_t)k]); });
+    const int rc = multi_each(h, [&](int k, dsim_sim *sh, int64_t) -> int { return dsim_get_signal_limbs(sh, &part[(size_t)k * L], &ne[(size_t)k]); });
     if (rc) return rc;
     int64_t total = 0;
-    for (size_t m = 0; m < M; m++) {
-      double a = 0, b = 0;
-      for (size_t k = 0; k < G; k++) a += c[k * M + m], b += sn[k * M + m];
-      out_cos[m] = a;
-      if (out_sin) out_sin[m] = b;
+    for (size_t q = 0; q < L; q++) {
+      int64_t t = 0;
+      for (size_t k = 0; k < G; k++) t += part[k * L + q];
+      limbs[q] = t;
     }
     for (size_t k = 0; k < G; k++) total += ne[k];
     if (n_exceeded) *n_exceeded = total;
     return DSIM_OK;
   }
-  if (!h || !out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
   HIP_TRY(hipSetDevice(h->device));
   dim3 grid(h->sig_blocks, h->M);
   signal_partial_kernel<<<grid, 256, 0, h->stream>>>(h->phase, h->exc, h->n, h->partial, h->nexc_partial);
   HIP_TRY(hipGetLastError());
   signal_final_kernel<<<h->M + 1, 64, 0, h->stream>>>(h->partial, h->nexc_partial, h->sig_blocks, h->M, h->sig_out);
   HIP_TRY(hipGetLastError());
-  std::vector<double> out((size_t)2 * h->M + 1);
-  HIP_TRY(hipMemcpyAsync(out.data(), h->sig_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<long long> out((size_t)4 * h->M + 1);
+  HIP_TRY(hipMemcpyAsync(out.data(), h->sig_out, out.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  for (int m = 0; m < h->M; m++) {
-    out_cos[m] = out[m];
-    if (out_sin) out_sin[m] = out[h->M + m];
-  }
-  if (n_exceeded) *n_exceeded = (int64_t)out[2 * h->M];
+  for (size_t q = 0; q < (size_t)4 * h->M; q++) limbs[q] = (int64_t)out[q];
+  if (n_exceeded) *n_exceeded = (int64_t)out[(size_t)4 * h->M];
   return DSIM_OK;
+}
+
+extern "C" int dsim_signal_from_limbs(int32_t M, const int64_t *limbs, double *out_cos, double *out_sin) {
+  if (M < 1 || !limbs || !out_cos) return fail(DSIM_ERR_INVALID, "dsim_signal_from_limbs: bad argument");
+  for (int m = 0; m < M; m++) {
+    out_cos[m] = signal_from_limbs(limbs[4 * m], limbs[4 * m + 1]);
+    if (out_sin) out_sin[m] = signal_from_limbs(limbs[4 * m + 2], limbs[4 * m + 3]);
+  }
+  return DSIM_OK;
+}
+
+extern "C" int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_exceeded) {
+  if (!h || !out_cos) return fail(DSIM_ERR_INVALID, "dsim_get_signal: null argument");
+  std::vector<int64_t> limbs((size_t)4 * (size_t)h->M);
+  const int rc = dsim_get_signal_limbs(h, limbs.data(), n_exceeded);
+  if (rc) return rc;
+  return dsim_signal_from_limbs(h->M, limbs.data(), out_cos, out_sin);
 }
 
 /* ------------------------------------------------------------------- mesh --- */
@@ -956,6 +975,7 @@ struct WalkGroup {
   int launch_no = 0;                      /* launch k uses counter set k & 1 */
   double *traj = nullptr;                 /* recorded mode: this group's [step][3][n] region of the handle's buffer */
   int32_t t_pos = 0;                      /* recorded mode: the time step the group has reached */
+  int32_t t_sorted = 0;                   /* recorded mode: the time step of the group's last re-sort */
   double clear_frac = -1;                 /* share of walkers in clear cells as of the last launch's sort (-1: unknown) */
   long long unfinished = 0, steps_left = 0, max_left = 0;
   double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
@@ -1012,7 +1032,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     }
     g.permuted = presorted; /* orig[] already holds the walkers' original indices */
     g.traj = recorded ? h->traj + (size_t)h->traj_steps * 3 * g.off : nullptr;
-    g.t_pos = t_begin;
+    g.t_pos = g.t_sorted = t_begin;
     g.unfinished = g.v.n;
     g.steps_left = (long long)g.v.n * (t_end - t_begin);
     g.max_left = t_end - t_begin;
@@ -1034,9 +1054,14 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     if (--g.launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
     if (recorded) {
       const int32_t ta = g.t_pos, tb = std::min<int32_t>(t_end, ta + std::min(resort, h->traj_steps));
-      int rc = resort_walkers(v, !g.permuted, false, 0, false, (int)(&g - grp));
-      if (rc) return rc;
-      g.permuted = true;
+      /* a launch is as long as the buffer of recorded positions allows (1e7 walkers: a few hundred steps); the walkers are
+       * re-sorted when they have moved `resort` steps since the last sort, not at every launch */
+      if (!g.permuted || ta - g.t_sorted >= resort) {
+        int rc = resort_walkers(v, !g.permuted, false, 0, false, (int)(&g - grp));
+        if (rc) return rc;
+        g.permuted = true;
+        g.t_sorted = ta;
+      }
       WalkParams q = p;
       const int c = v->cur;
       q.n = v->n;
@@ -1369,9 +1394,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   }
   h->rec_t0 = h->rec_t1 = 0;
   if (record) {
-    /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps
-     * per launch; a recording run must hold its whole range */
-    const int64_t fit = (int64_t)(32ull << 30) / (h->n * 24);
+    /* up to 32 GB of recorded positions for a recording run, which must hold its whole range (24 bytes per walker and
+     * step); the internal recordings of runs with many measurements take up to 64 GB of the MI355X's 288 GB (1e7
+     * walkers: 286 steps per launch), at most 1024 steps per launch */
+    const int64_t fit = (int64_t)((h->recording ? 32ull : 64ull) << 30) / (h->n * 24);
     int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, fit));
     steps = std::min(steps, std::max(16, t_end - t_begin)); /* no more than this run needs */
     if (h->recording) {

@@ -815,84 +815,92 @@ DSD double wave_sum(double v) {
   return v;
 }
 
-/* grid = (blocks, M); partial[(m*gridDim.x + b)*2 + {0,1}] = block sums of cos, sin;
+/* The sum over walkers is taken EXACTLY: every term cos(phase), sin(phase) is rounded once to a multiple of 2^-60
+ * (exact for |term| >= 2^-8, an absolute error below 2^-61 otherwise) and the multiples are added as integers, split
+ * into a high and a low limb of 30 bits so that 2^33 terms fit 64-bit accumulators: q = hi * 2^30 + lo, 0 <= lo < 2^30.
+ * Integer addition is associative, so the signal does not depend on how the walkers are cut into threads, workgroups,
+ * shards, devices or ranks - an 8-GPU job returns the bytes of the 1-GPU job (the reference adds the doubles up with
+ * numpy's pairwise sum on the host, simulations.py:1413-1421; the exact sum is within N * 2^-61 of the true one).
+ * Walkers with iter_exc set or a NaN phase contribute nothing (the reference's NaN mask + nansum). */
+#define DS_SIG_SCALE 0x1p60
+#define DS_SIG_LIMB_BITS 30
+
+DSD long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int lo = __shfl_down((int)(v & 0xffffffffLL), off, 64), hi = __shfl_down((int)(v >> 32), off, 64);
+    v += ((long long)hi << 32) | (long long)(unsigned)lo;
+  }
+  return v;
+}
+
+/* grid = (blocks, M); partial[(m*gridDim.x + b)*4 + {0..3}] = block sums of the limbs {cos hi, cos lo, sin hi, sin lo};
  * the m == 0 row also counts the exceeded walkers into nexc_partial[b].
- * Replaces phases D2H + np.nansum(np.exp(1j*phases)) (simulations.py:1413-1421):
- * walkers with iter_exc set or a NaN phase contribute nothing. */
+ * Replaces phases D2H + np.nansum(np.exp(1j*phases)) (simulations.py:1413-1421). */
 __global__ __launch_bounds__(256) void signal_partial_kernel(const double *phase, const uint8_t *exc, int64_t n,
-                                                             double *partial, double *nexc_partial) {
-  __shared__ double sc[4], ss[4], se[4];
+                                                             long long *partial, long long *nexc_partial) {
+  __shared__ long long sm[4][5];
   const int m = blockIdx.y;
-  double c = 0, s = 0, e = 0;
+  long long ch = 0, cl = 0, sh = 0, sl = 0, e = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double ph = phase[(int64_t)m * n + i];
     const bool x = exc[i] != 0;
-    e += x ? 1.0 : 0.0;
+    e += x ? 1 : 0;
     if (!x && ph == ph) {
       double sv, cv;
       sincos(ph, &sv, &cv);
       if (sv == sv && cv == cv) {
-        c += cv;
-        s += sv;
+        const long long qc = (long long)__builtin_rint(cv * DS_SIG_SCALE), qs = (long long)__builtin_rint(sv * DS_SIG_SCALE);
+        ch += qc >> DS_SIG_LIMB_BITS, cl += qc & ((1LL << DS_SIG_LIMB_BITS) - 1);
+        sh += qs >> DS_SIG_LIMB_BITS, sl += qs & ((1LL << DS_SIG_LIMB_BITS) - 1);
       }
     }
   }
-  c = wave_sum(c);
-  s = wave_sum(s);
-  e = wave_sum(e);
+  ch = wave_sum_i64(ch), cl = wave_sum_i64(cl), sh = wave_sum_i64(sh), sl = wave_sum_i64(sl), e = wave_sum_i64(e);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-    sc[wave] = c;
-    ss[wave] = s;
-    se[wave] = e;
-  }
+  if (lane == 0) sm[wave][0] = ch, sm[wave][1] = cl, sm[wave][2] = sh, sm[wave][3] = sl, sm[wave][4] = e;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double tc = 0, ts = 0, te = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
-      tc += sc[w];
-      ts += ss[w];
-      te += se[w];
-    }
-    partial[((int64_t)m * gridDim.x + blockIdx.x) * 2] = tc;
-    partial[((int64_t)m * gridDim.x + blockIdx.x) * 2 + 1] = ts;
-    if (m == 0) nexc_partial[blockIdx.x] = te;
+  if (threadIdx.x < 5) {
+    long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += sm[w][threadIdx.x];
+    if (threadIdx.x < 4)
+      partial[((int64_t)m * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = t;
+    else if (m == 0)
+      nexc_partial[blockIdx.x] = t;
   }
 }
 
-/* one wavefront per measurement folds the block partials in a fixed order
- * (deterministic, no float atomics); block M folds the exceeded-walker counts. */
-__global__ __launch_bounds__(64) void signal_final_kernel(const double *partial, const double *nexc_partial, int n_blocks,
-                                                          int M, double *out /* [2M + 1] */) {
+/* one wavefront per measurement adds the block partials up (integers: any order gives the same sums); block M adds
+ * the exceeded-walker counts.  out: [4 M + 1] = per measurement {cos hi, cos lo, sin hi, sin lo}, then the count */
+__global__ __launch_bounds__(64) void signal_final_kernel(const long long *partial, const long long *nexc_partial, int n_blocks,
+                                                          int M, long long *out /* [4M + 1] */) {
   const int m = blockIdx.x;
   if (m < M) {
-    double c = 0, s = 0;
-    for (int b = threadIdx.x; b < n_blocks; b += 64) {
-      c += partial[((int64_t)m * n_blocks + b) * 2];
-      s += partial[((int64_t)m * n_blocks + b) * 2 + 1];
-    }
-    c = wave_sum(c);
-    s = wave_sum(s);
-    if (threadIdx.x == 0) {
-      out[m] = c;
-      out[M + m] = s;
-    }
+    long long t[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < n_blocks; b += 64)
+#pragma unroll
+      for (int q = 0; q < 4; q++) t[q] += partial[((int64_t)m * n_blocks + b) * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) t[q] = wave_sum_i64(t[q]);
+    if (threadIdx.x == 0)
+      for (int q = 0; q < 4; q++) out[4 * m + q] = t[q];
   } else {
-    double cnt = 0;
+    long long cnt = 0;
     for (int b = threadIdx.x; b < n_blocks; b += 64) cnt += nexc_partial[b];
-    cnt = wave_sum(cnt);
-    if (threadIdx.x == 0) out[2 * M] = cnt;
+    cnt = wave_sum_i64(cnt);
+    if (threadIdx.x == 0) out[4 * M] = cnt;
   }
 }
 
 /* all_signals (simulations.py:1414-1417): out[e] = cos(phase[first + e]) for the elements [first, first + count) of
- * the flattened (M, n) phase matrix, NaN where the walker's iter_exc flag is set */
+ * the flattened (M, n) phase matrix, NaN where the walker's iter_exc flag is set.  grid = (walkers / 256, rows the
+ * range touches): blockIdx.y names the measurement, so the walker index needs no 64-bit modulo per element. */
 __global__ __launch_bounds__(256) void all_signals_kernel(const double *phase, const uint8_t *exc, int64_t n, int64_t first,
-                                                          int64_t count, double *out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= count) return;
-  const int64_t i = (first + e) % n;
-  out[e] = exc[i] != 0 ? DS_NAN : cos(phase[first + e]);
+                                                          int64_t count, int64_t first_row, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t flat = (first_row + blockIdx.y) * n + i;
+  if (i >= n || flat < first || flat >= first + count) return;
+  out[flat - first] = exc[i] != 0 ? DS_NAN : cos(phase[flat]);
 }
 
 /* ---- layout conversion ---------------------------------------------------------- */

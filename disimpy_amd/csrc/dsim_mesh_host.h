@@ -465,14 +465,20 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   std::vector<float4> mrec;
   cell_start.reserve((size_t)(lk > 0 ? n_nonempty * slots : n_sub) + 1);
   {
-    std::vector<std::vector<int32_t>> cells;
-    std::vector<float> lo3, hi3;
-    for (int64_t s = 0; s < n_sub; s++) {
+    /* per non-empty subvoxel: the record count of every slot and the records, built by a few host threads (the subvoxels are
+     * independent), then strung together in subvoxel order */
+    struct Built {
+      std::vector<uint32_t> count; /* [slots] */
+      std::vector<float4> recs;
+    };
+    std::vector<int64_t> todo;
+    for (int64_t s = 0; s < n_sub; s++)
+      if (ranges[s].y > ranges[s].x) todo.push_back(s);
+    std::vector<Built> built(todo.size());
+    auto build_one = [&](size_t tn, std::vector<std::vector<int32_t>> &cells, std::vector<float> &lo3, std::vector<float> &hi3) {
+      const int64_t s = todo[tn];
+      Built &out = built[tn];
       const int begin = ranges[s].x, end = ranges[s].y, n_s = end - begin;
-      if (n_s <= 0) {
-        if (lk == 0) cell_start.push_back((uint32_t)(mrec.size() / 3)); /* dense over the subvoxels: an empty range */
-        continue;
-      }
       const int64_t sx = s / (n_sv[1] * n_sv[2]), sy = (s / n_sv[2]) % n_sv[1], sz = s % n_sv[2];
       const double org[3] = {xs[sx], ys[sy], zs[sz]};
       const double scale[3] = {(double)nun[0] * inv_h3[0], (double)nun[1] * inv_h3[1], (double)nun[2] * inv_h3[2]}; /* units per metre */
@@ -504,11 +510,11 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
               cells[((size_t)a * nun[1] + b) * nun[2] + c].push_back(i);
             }
       }
-      if (lk > 0) sv_base[s] = (int32_t)cell_start.size();
+      out.count.assign(slots, 0u);
       for (size_t ci = 0; ci < cells.size(); ci++) {
         auto &cl = cells[ci];
         const int abc[3] = {(int)(ci / ((size_t)nun[1] * nun[2])), (int)((ci / nun[2]) % nun[1]), (int)(ci % nun[2])};
-        cell_start.push_back((uint32_t)(mrec.size() / 3));
+        out.count[ci] = (uint32_t)cl.size();
         for (int32_t i : cl) {
           float lo[3], hi[3];
           for (int ax = 0; ax < 3; ax++) lo[ax] = lo3[(size_t)(i - begin) * 3 + ax], hi[ax] = hi3[(size_t)(i - begin) * 3 + ax];
@@ -540,11 +546,46 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
             fz = (float)(nz / nn);
             fc = (float)((double)fx * r[0] + (double)fy * r[1] + (double)fz * r[2]);
           }
-          mrec.push_back(make_float4(lo[0], lo[1], lo[2], hi[0]));
-          mrec.push_back(make_float4(hi[1], hi[2], fx, fy));
-          mrec.push_back(make_float4(fz, fc, idx_bits, pos_bits));
+          out.recs.push_back(make_float4(lo[0], lo[1], lo[2], hi[0]));
+          out.recs.push_back(make_float4(hi[1], hi[2], fx, fy));
+          out.recs.push_back(make_float4(fz, fc, idx_bits, pos_bits));
         }
       }
+    };
+    {
+      const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), (int64_t)todo.size() / 16));
+      std::atomic<size_t> next(0);
+      auto worker = [&]() {
+        std::vector<std::vector<int32_t>> cells;
+        std::vector<float> lo3, hi3;
+        for (;;) {
+          const size_t tn = next.fetch_add(1);
+          if (tn >= todo.size()) break;
+          build_one(tn, cells, lo3, hi3);
+        }
+      };
+      if (n_thr <= 1) {
+        worker();
+      } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_thr; t++) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+      }
+    }
+    size_t tn = 0;
+    for (int64_t s = 0; s < n_sub; s++) {
+      if (ranges[s].y <= ranges[s].x) {
+        if (lk == 0) cell_start.push_back((uint32_t)(mrec.size() / 3)); /* dense over the subvoxels: an empty range */
+        continue;
+      }
+      const Built &bu = built[tn++];
+      if (lk > 0) sv_base[s] = (int32_t)cell_start.size();
+      uint32_t at = (uint32_t)(mrec.size() / 3);
+      for (size_t ci = 0; ci < slots; ci++) {
+        cell_start.push_back(at);
+        at += bu.count[ci];
+      }
+      mrec.insert(mrec.end(), bu.recs.begin(), bu.recs.end());
     }
     if (mrec.size() / 3 >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
     cell_start.push_back((uint32_t)(mrec.size() / 3)); /* end of the last cell */

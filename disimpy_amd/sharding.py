@@ -5,8 +5,9 @@ final signal sum.  GPU g of G owns a contiguous global walker range of
 floor(N/G) or floor(N/G)+1 walkers (balanced split; a rank whose range is empty
 skips the GPU work and contributes zeros); walker i ALWAYS uses RNG state i and
 initial position i, so results do not depend on G except for floating-point
-summation order.  The single collective is one all-reduce (sum, float64,
-2*M + 1 values: sum cos, sum sin, exceeded-walker count) over
+summation order - and not even for that: the device adds the signal up exactly, as integers
+(include/dsim.h, dsim_get_signal_limbs).  The single collective is one all-reduce (sum, int64,
+4*M + 1 values: two limbs per cos / sin sum, exceeded-walker count) over
 ``torch.distributed`` - backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
 CPU tests.  Payload <= ~1.6 KB: latency only, link bandwidth is irrelevant.
 
@@ -43,6 +44,26 @@ def reduce_signal(cos_sum, sin_sum, n_exceeded, dist=None, device=None):
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     out = buf.cpu().numpy()
     return out[:M], out[M : 2 * M], int(round(out[2 * M]))
+
+
+def reduce_signal_exact(limbs, n_exceeded, dist=None, device=None):
+    """All-reduce of the EXACT signal sums: ``limbs`` = the (4 M,) int64 of ``_lib.Sim.signal_limbs()`` (every term rounded
+    to a multiple of 2^-60, summed as integers in two limbs per sum).  Integer sums are the same in any order, so the
+    all-reduced total - turned into doubles by ``_lib.signal_from_limbs`` on every rank - is bit for bit what one GPU
+    returns for all the walkers.  One collective of 4 M + 1 int64 (RCCL / gloo).  Returns (cos, sin, n_exceeded)."""
+    from . import _lib
+
+    buf = np.concatenate([np.asarray(limbs, dtype=np.int64), [int(n_exceeded)]])
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+
+        t = torch.from_numpy(buf)
+        if dist.get_backend() == "nccl":
+            t = t.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        buf = t.cpu().numpy()
+    c, s = _lib.signal_from_limbs(buf[:-1])
+    return c, s, int(buf[-1])
 
 
 def _all_gather(arr, dist, device=None):
@@ -175,12 +196,15 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
         if world > 1 and substrate.type == "mesh" and isinstance(substrate.init_pos, str) and substrate.init_pos in ("intra", "extra"):
             simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (a, b), dist=dist)  # the shared fill
         res = {"cos": np.zeros(M), "sin": np.zeros(M), "n_exceeded": 0, "iter_exc": np.zeros(0, dtype=bool),
-               "all_signals": np.zeros((M, 0)), "positions": np.zeros((0, 3))}
+               "all_signals": np.zeros((M, 0)), "positions": np.zeros((0, 3)), "limbs": np.zeros(4 * M, dtype=np.int64)}
     else:
         res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, max_iter, epsilon,
                                     device=device or 0, walker_range=(a, b), dist=dist if world > 1 else None,
                                     need_phases=bool(all_signals), need_positions=bool(final_pos))
-    c, s, nexc = reduce_signal(res["cos"], res["sin"], res["n_exceeded"], dist, device)
+    if "limbs" in res:  # the exact integer sums of the device reduction: the total does not depend on the split
+        c, s, nexc = reduce_signal_exact(res["limbs"], res["n_exceeded"], dist, device)
+    else:
+        c, s, nexc = reduce_signal(res["cos"], res["sin"], res["n_exceeded"], dist, device)
     if nexc:  # rare: the flags of all walkers, for the warning text (same on every rank)
         exc = _gather_rows(res["iter_exc"].astype(np.uint8), dist, device).astype(bool) if world > 1 else res["iter_exc"]
         if np.any(exc):

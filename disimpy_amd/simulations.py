@@ -339,7 +339,8 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
                 sys.stdout.write(f"\r{np.round((t0 / n_t) * 100, 1)}%")
                 sys.stdout.flush()
         out = {"device_ms": ms_total, "range": (a, b)}
-        out["cos"], out["sin"], out["n_exceeded"] = sim.signal()
+        out["limbs"], out["n_exceeded"] = sim.signal_limbs()  # exact integer sums: limbs of shards / ranks add
+        out["cos"], out["sin"] = _lib.signal_from_limbs(out["limbs"])
         out["iter_exc"] = sim.iter_exc() if out["n_exceeded"] else np.zeros(b - a, dtype=bool)
         if need_phases:  # all_signals: real(exp(1j * phases)) with the NaN mask, evaluated on the device (:1414-1417)
             out["all_signals"] = sim.all_signals()

@@ -101,9 +101,9 @@ int dsim_create(dsim_handle *out, int device, int64_t n_walkers, int64_t first_w
  * range k lives on device device_ids[k] (a device may be named more than once: several shards on one GPU).  Every
  * other entry point of this header takes the handle as it takes a dsim_create handle: host arrays cover all
  * n_walkers walkers in order (each shard reads / fills its slice), dsim_run_* advance the shards concurrently (one
- * host thread per shard), dsim_get_signal adds the shards' sums on the host in shard order, dsim_write_traj writes
- * lines that hold every walker.  Walker i uses RNG state i and initial position i whatever the split, so per-walker
- * outputs are identical to a single-device run bit for bit and the signal differs by summation order only.  No
+ * host thread per shard), dsim_get_signal adds the shards' exact integer sums (dsim_get_signal_limbs), dsim_write_traj
+ * writes lines that hold every walker.  Walker i uses RNG state i and initial position i whatever the split, so every
+ * output - per-walker arrays and the signal - is identical to a single-device run bit for bit.  No
  * torch, no process group: one process drives all devices. */
 int dsim_create_multi(dsim_handle *out, const int32_t *device_ids, int32_t n_devices, int64_t n_walkers, int64_t first_walker,
                       int32_t M, int32_t T, const double *gx, const double *gy, const double *gz, double dt, double step_l);
@@ -150,6 +150,16 @@ int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, double perm_p
  * n_exceeded = number of walkers with iter_exc set.  out_sin / n_exceeded may
  * be NULL. */
 int dsim_get_signal(dsim_handle h, double *out_cos, double *out_sin, int64_t *n_exceeded);
+
+/* The same sums before the final rounding.  The device adds every term up EXACTLY: cos / sin of a phase is rounded once
+ * to a multiple of 2^-60 and the multiples are summed as integers, kept in two limbs per sum (q = hi * 2^30 + lo, each
+ * limb an int64 that holds 2^33 terms).  limbs[4 m + {0, 1, 2, 3}] = {cos hi, cos lo, sin hi, sin lo} of measurement m.
+ * Integer sums do not depend on the order of the additions: limbs of shards, devices or ranks simply ADD (one all-reduce
+ * of 4 M + 1 int64 over RCCL), and dsim_signal_from_limbs turns the totals into the doubles dsim_get_signal returns
+ * (exact sum, rounded once) - so a job cut over 8 GPUs returns the bytes of the 1-GPU job, whatever the cut.
+ * dsim_signal_from_limbs needs no handle and no GPU. */
+int dsim_get_signal_limbs(dsim_handle h, int64_t *limbs, int64_t *n_exceeded);
+int dsim_signal_from_limbs(int32_t M, const int64_t *limbs, double *out_cos, double *out_sin);
 
 /* Per-walker outputs for final_pos / traj / all_signals / the warning text. */
 int dsim_get_positions(dsim_handle h, double *positions_aos);        /* (n_walkers,3), :1212, :1426 */

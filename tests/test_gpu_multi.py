@@ -1,8 +1,9 @@
 """Several GPUs behind the ONE drop-in call (``-m gpu``): ``simulations.simulation`` spreads its walkers over every
 visible device through a multi-device handle of the C ABI (include/dsim.h, dsim_create_multi) - no ranks, no torch.
 On the driver's one-GPU box the device list names device 0 twice (two or three shards on the one GPU, DSIM_DEVICES):
-every per-walker output must be the single-shard run's bytes (walker i <- RNG state i and initial position i whatever
-the split; reference outputs: disimpy/simulations.py:1406-1429), the signal its sum in another order."""
+every output must be the single-shard run's bytes - per-walker arrays (walker i <- RNG state i and initial position i
+whatever the split; reference outputs: disimpy/simulations.py:1406-1429) and the signal, which the device
+adds up exactly as integers (dsim_get_signal_limbs)."""
 import os
 import sys
 import warnings
@@ -57,7 +58,7 @@ def test_shards_on_one_gpu_return_the_single_shard_outputs(mods, devices):
         (sig1, pos1), w1 = _run(simulations, "0", n, gradient, dt, sub, kw, final_pos=True)
         (sig2, pos2), w2 = _run(simulations, devices, n, gradient, dt, sub, kw, final_pos=True)
         assert pos1.tobytes() == pos2.tobytes(), name
-        np.testing.assert_allclose(sig2, sig1, rtol=0, atol=1e-12 * n, err_msg=name)  # summation order only
+        assert sig1.tobytes() == sig2.tobytes(), name  # the device adds the signal up exactly (integer limbs): no summation order
         assert w1 == w2, name  # the warning text names the same global walker indices
         if "iteration" in name:
             assert len(w1) == 1 and "walkers [" in w1[0]
@@ -109,9 +110,16 @@ def test_multi_device_handle_state_round_trips(mods):
             np.testing.assert_array_equal(multi.recorded(3, 17), one.recorded(3, 17))
             c2, s2, e2 = multi.signal()
             c1, s1, e1 = one.signal()
-            np.testing.assert_allclose(c2, c1, rtol=0, atol=1e-12 * n)
-            np.testing.assert_allclose(s2, s1, rtol=0, atol=1e-12 * n)
-            assert e1 == e2
+            assert c1.tobytes() == c2.tobytes() and s1.tobytes() == s2.tobytes() and e1 == e2
+            np.testing.assert_array_equal(multi.signal_limbs()[0], one.signal_limbs()[0])
+            # the exact sum against the host's correctly rounded sum of the same terms (device cos of the device's phases:
+            # all_signals), term by term rounded to 2^-60 as the device does
+            import math
+            sig = one.all_signals()
+            for m in range(sig.shape[0]):
+                terms = sig[m][~np.isnan(sig[m])]
+                want = math.fsum(np.rint(terms * 2.0**60) / 2.0**60)
+                assert abs(c1[m] - want) <= 1e-15 * max(1.0, abs(want)), (m, c1[m], want)
     with pytest.raises(_lib.DsimError, match="shard 1 on device 7"):
         _lib.Sim(10, gradient, dt, step_l, devices=[0, 7])
 
@@ -126,5 +134,4 @@ def test_every_visible_gpu_is_used_by_default(mods):
     assert simulations._default_devices(_lib.device_count()) == list(range(_lib.device_count()))
     sig, pos = simulations.simulation(n, D, gradient, dt, substrates.sphere(5e-6), seed=5, quiet=True, final_pos=True)
     (sig1, pos1), _ = _run(simulations, "0", n, gradient, dt, substrates.sphere(5e-6), {}, final_pos=True)
-    assert pos.tobytes() == pos1.tobytes()
-    np.testing.assert_allclose(sig, sig1, rtol=0, atol=1e-12 * n)
+    assert pos.tobytes() == pos1.tobytes() and sig.tobytes() == sig1.tobytes()

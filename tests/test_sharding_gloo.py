@@ -89,6 +89,18 @@ def test_two_rank_gloo_reduce_matches_single_process():
     np.testing.assert_array_equal(got[0][1], got[1][1])  # every rank holds the same total
 
 
+def _limbs(ph, exc):
+    """numpy restatement of the device's exact signal sums (dsim_kernels.h, signal_partial_kernel): every cos / sin
+    term rounded to a multiple of 2^-60, summed as integers in two limbs of 30 bits"""
+    out = []
+    keep = ~np.asarray(exc, dtype=bool)
+    for m in range(len(ph)):
+        for f in (np.cos, np.sin):
+            q = [int(v) for v in np.rint(f(ph[m][keep]) * 2.0**60)]
+            out += [sum(v >> 30 for v in q), sum(v & (2**30 - 1) for v in q)]
+    return np.array(out, dtype=np.int64)
+
+
 def _worker_empty(rank, world, port, n, q):
     """More ranks than walkers: the rank with an empty range goes through simulation_sharded() itself (it must
     not touch the GPU and must still take part in the collective), the others stand in with the oracle."""
@@ -109,8 +121,7 @@ def _worker_empty(rank, world, port, n, q):
         st = o.rng_states(b, 123)[a:].copy()
         pos = np.zeros((b - a, 3))
         ph, exc, _ = o.run(o.geom(FREE), gradient, dt, step_l, pos, st)
-        c, s = o.signal(ph, exc)
-        tc, _, _ = sharding.reduce_signal(c, s, 0, dist)
+        tc, _, _ = sharding.reduce_signal_exact(_limbs(ph, exc), 0, dist)
     q.put((rank, (a, b), tc))
     dist.barrier()
     dist.destroy_process_group()
