@@ -424,9 +424,28 @@ def secondary_rates(args, device):
         run_steps(sim, sub, w["frames"], T, 1, None, device, lambda: None)
         el, walk_ms, _, _, sig = run_steps(sim, sub, w["frames"], T, 2, None, device, lambda: None)
         sim.close()
+        walk_rate = n * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)
         out[key] = {"workload": w["label"], "value": n * T * 2 / el, "unit": "spin-steps/s",
-                     "walk_kernel_spin_steps_per_s": n * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)}
+                     "walk_kernel_spin_steps_per_s": walk_rate, "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=walk_rate)}
     return out
+
+
+def valu_roofline(workload, M, walk_rate):
+    """The bound that holds for a register-resident fused kernel: vector-ALU issue.  SURVEY 8d's byte model does not
+    apply to these configurations (C2 at 6e10 spin-steps/s x 592 B would be 4.8 x the HBM peak: the fused kernel does not
+    move those bytes), so the secondary entries carry the VALU figures of their own kernels instead: wave-instructions
+    per wavefront-step and the measured VALU-busy share from the committed counter run (profiles/kernel_counters.json,
+    tools/pmc_profile.py) - quoted only when those counters were taken on THIS build of the library - and the issue rate
+    this run's throughput implies against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction."""
+    prof = profile_entry(workload) or {}
+    ok = bool(prof) and prof.get("lib_sha256") == lib_sha256() and prof.get("measurements", 1) in (1, M)
+    use = prof if ok else {}
+    valu_ws = use.get("valu_per_wave_step")
+    rate = valu_ws * walk_rate / 64.0 if valu_ws else None
+    return {"bound": "valu", "kernel": use.get("kernel"), "valu_per_wave_step": valu_ws, "valu_busy_measured": use.get("valu_busy"),
+            "salu_per_wave_step": use.get("salu_per_wave_step"), "lds_per_wave_step": use.get("lds_per_wave_step"),
+            "achieved": rate, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": (rate / VALU_PEAK) if rate else None,
+            "counters_match_lib": ok, "counters_source": prof.get("source")}
 
 
 def launch_ranks(n_ranks, argv, script=None):

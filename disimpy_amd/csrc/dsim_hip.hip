@@ -5,7 +5,6 @@
  * gfx950 only, with -ffp-contract=off (see dsim_device.h).
  */
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -1054,9 +1053,11 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     if (--g.launches_left < 0) return fail(DSIM_ERR_STATE, "mesh run makes no progress");
     if (recorded) {
       const int32_t ta = g.t_pos, tb = std::min<int32_t>(t_end, ta + std::min(resort, h->traj_steps));
-      /* a launch is as long as the buffer of recorded positions allows (1e7 walkers: a few hundred steps); the walkers are
-       * re-sorted when they have moved `resort` steps since the last sort, not at every launch */
-      if (!g.permuted || ta - g.t_sorted >= resort) {
+      /* a launch is as long as the buffer of recorded positions allows (1e7 walkers: 143 steps) and every launch starts
+       * with a re-sort: measured on C5b at 1e7 walkers with 32 measurements, sorting only every `resort` steps and
+       * recording 286 steps per launch (64 GB) ran at 9.2e9 against 1.05e10 (profiles/history/r04_ab_m32_*) - without
+       * per-walker clocks the wavefronts of a launch stay in step, and freshly sorted walkers keep their passes alike */
+      {
         int rc = resort_walkers(v, !g.permuted, false, 0, false, (int)(&g - grp));
         if (rc) return rc;
         g.permuted = true;
@@ -1381,10 +1382,12 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
        * per launch the sorts themselves weigh more.  Measured on C5b with two walker groups (resort 1024 -> 256):
        * +3.6 % at 1.25e6 walkers, +0.9 % on C4 at 1e6; at 1e7 walkers 1024 -> 512 costs 0.8 %. */
       const double rounds = (double)h->n / (double)walker_groups(h) / 64.0 / 4096.0;
-      if (coop4 && rounds < 4.0)
-        resort = std::min(resort, 256);
-      else if (coop4 && rounds < 10.0)
-        resort = std::min(resort, 512);
+      /* [r4] With the fine grid of overlapping cells (2.5 times the records of round 3's, every walker reading the one
+       * list around it) a wavefront whose walkers have drifted apart pays more, and sorting more often pays: C5b at 1e7
+       * walkers 1.47 / 1.53 / 1.53 / 1.50 / 1.43e10 for 1024 / 512 / 256 / 128 / 64 steps, at 1.25e6 walkers
+       * 1.285 / 1.32 / 1.34 / 1.33 / 1.27e10 for 512 / 256 / 128 / 64 / 32, C4 at 1e6 walkers 1.13 / 1.15 / 1.175e10 for
+       * 512 / 256 / 128 (profiles/history/r04_sweeps_resort_interval.txt) */
+      if (coop4) resort = std::min(resort, rounds < 6.0 ? 128 : 256);
     }
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
@@ -1394,10 +1397,9 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   }
   h->rec_t0 = h->rec_t1 = 0;
   if (record) {
-    /* up to 32 GB of recorded positions for a recording run, which must hold its whole range (24 bytes per walker and
-     * step); the internal recordings of runs with many measurements take up to 64 GB of the MI355X's 288 GB (1e7
-     * walkers: 286 steps per launch), at most 1024 steps per launch */
-    const int64_t fit = (int64_t)((h->recording ? 32ull : 64ull) << 30) / (h->n * 24);
+    /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps
+     * per launch; a recording run must hold its whole range */
+    const int64_t fit = (int64_t)(32ull << 30) / (h->n * 24);
     int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, fit));
     steps = std::min(steps, std::max(16, t_end - t_begin)); /* no more than this run needs */
     if (h->recording) {
@@ -1979,26 +1981,6 @@ extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, do
 
 /* -------------------------------------------------------------- fill_mesh --- */
 
-/* accepted point i of this launch goes to row have + prefix[i] (rows beyond n are dropped); the last thread leaves
- * the new count in the other slot of `have` (two slots, alternating, so that nobody reads what it writes) */
-__global__ void fill_scatter_kernel(const double *px, const double *py, const double *pz, const int32_t *flag, const int32_t *pref,
-                                    int64_t n, int64_t capacity, const int64_t *have_in, int64_t *have_out, int64_t *count_out, double *out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t base = *have_in;
-  if (i == n - 1) {
-    *have_out = base + pref[i] + flag[i];
-    *count_out = (int64_t)pref[i] + flag[i];
-  }
-  if (!flag[i]) return;
-  int64_t row = base + pref[i];
-  if (row < capacity) {
-    out[row * 3] = px[i];
-    out[row * 3 + 1] = py[i];
-    out[row * 3 + 2] = pz[i];
-  }
-}
-
 /* A fill session: the device state of the _fill_mesh loop (simulations.py:505-579) for a RANGE of its threads.
  * The reference launches _cuda_fill_mesh over n_points threads again and again - every thread draws one candidate
  * per launch from its own RNG state - and appends the accepted points of a launch in thread order until n_points
@@ -2011,19 +1993,20 @@ struct dsim_fill {
   hipStream_t stream = nullptr;
   DevMesh dm;
   int64_t n_threads = 0;
-  double *px = nullptr, *py = nullptr, *pz = nullptr;
   uint64_t *s0 = nullptr, *s1 = nullptr;
+  uint64_t *s0_keep = nullptr, *s1_keep = nullptr; /* the states as they were before the current batch (a batch that overflows is redone) */
   int32_t *d_col_start = nullptr, *d_mstart = nullptr;
   int2 *d_col_ent = nullptr, *d_ent = nullptr, *d_mcol = nullptr, *d_ment = nullptr;
   float4 *d_ent_yz = nullptr, *d_ment_yz = nullptr;
-  int32_t *d_flag = nullptr, *d_pref = nullptr;
-  int64_t *d_have = nullptr;   /* [2]: rows written so far, alternating slots */
-  int64_t *d_counts = nullptr; /* accepted points of every launch of the current run */
-  int64_t counts_cap = 0;
-  double *d_out = nullptr;     /* accepted points of the current run, in (launch, thread) order */
+  /* a batch of launches = three dispatches (fill_batch_kernel, fill_scan_kernel, fill_place_kernel; dsim_kernels.h) */
+  int n_blocks = 0, stage_cap = 0;
+  FillEntry *d_stage = nullptr;     /* [n_blocks][stage_cap] */
+  int32_t *d_stage_count = nullptr; /* [n_blocks] */
+  int32_t *d_cnt = nullptr;         /* [FILL_MAX_BATCH][n_blocks] */
+  int64_t *d_totals = nullptr;      /* [FILL_MAX_BATCH] accepted per launch of the batch, then [1] the overflow flag (as int32) */
+  int32_t *d_overflow = nullptr;
+  double *d_out = nullptr;          /* accepted points of the current run, in (launch, thread) order */
   int64_t out_cap = 0;
-  void *d_tmp = nullptr;
-  size_t tmp_bytes = 0;
   FillParams fp;
   size_t lds = 0;
   int64_t launches = 0;
@@ -2034,8 +2017,8 @@ extern "C" int dsim_fill_close(dsim_fill *fs) {
   (void)hipSetDevice(fs->device);
   if (fs->stream) (void)hipStreamSynchronize(fs->stream);
   free_mesh(fs->dm);
-  void *ptrs[] = {fs->px, fs->py, fs->pz, fs->s0, fs->s1, fs->d_col_start, fs->d_mstart, fs->d_col_ent, fs->d_ent, fs->d_mcol, fs->d_ment,
-                  fs->d_ent_yz, fs->d_ment_yz, fs->d_flag, fs->d_pref, fs->d_have, fs->d_counts, fs->d_out, fs->d_tmp};
+  void *ptrs[] = {fs->s0, fs->s1, fs->s0_keep, fs->s1_keep, fs->d_col_start, fs->d_mstart, fs->d_col_ent, fs->d_ent, fs->d_mcol, fs->d_ment,
+                  fs->d_ent_yz, fs->d_ment_yz, fs->d_stage, fs->d_stage_count, fs->d_cnt, fs->d_totals, fs->d_overflow, fs->d_out};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   if (fs->stream) (void)hipStreamDestroy(fs->stream);
@@ -2052,11 +2035,10 @@ static int fill_open_impl(dsim_fill *fs, int64_t thread_begin, int intra, uint64
   HIP_TRY(hipStreamCreateWithFlags(&fs->stream, hipStreamNonBlocking));
   int rc = upload_mesh(fs->dm, fs->stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, 0.0);
   if (rc) return rc;
-  HIP_TRY(hipMalloc(&fs->px, n * sizeof(double)));
-  HIP_TRY(hipMalloc(&fs->py, n * sizeof(double)));
-  HIP_TRY(hipMalloc(&fs->pz, n * sizeof(double)));
   HIP_TRY(hipMalloc(&fs->s0, n * sizeof(uint64_t)));
   HIP_TRY(hipMalloc(&fs->s1, n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&fs->s0_keep, n * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(&fs->s1_keep, n * sizeof(uint64_t)));
   /* own RNG states with the same seed (simulations.py:524): thread i <- state i, whatever the range */
   {
     const JumpTables &jt = jump_tables();
@@ -2203,21 +2185,28 @@ static int fill_open_impl(dsim_fill *fs, int64_t thread_begin, int intra, uint64
   fp.ment = fs->d_ment;
   fp.ment_yz = fs->d_ment_yz;
   fp.n_points = n;
-  fp.px = fs->px;
-  fp.py = fs->py;
-  fp.pz = fs->pz;
   fp.s0 = fs->s0;
   fp.s1 = fs->s1;
   fp.intra = intra ? 1 : 0;
   for (int k = 0; k < 3; k++) fp.voxel[k] = voxel_size[k];
   fp.mesh = mesh_dev(fs->dm);
   fs->lds = (size_t)(fs->dm.nx + fs->dm.ny + fs->dm.nz + 3) * sizeof(double);
-  HIP_TRY(hipMalloc(&fs->d_flag, n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&fs->d_pref, n * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&fs->d_have, 2 * sizeof(int64_t)));
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, fs->tmp_bytes, fs->d_flag, fs->d_pref, (int)n, fs->stream));
-  HIP_TRY(hipMalloc(&fs->d_tmp, fs->tmp_bytes));
-  fp.flag = fs->d_flag;
+  /* staging rows per workgroup: a batch is sized (by the callers' batch rule) so that it accepts about as many points as
+   * are still wanted, i.e. at most ~256 per workgroup; 1024 leaves room for an estimate that is off by a factor of four,
+   * and a batch that overflows all the same is redone launch by launch (never more than 256 per workgroup) */
+  fs->n_blocks = grid_for(n, 256);
+  fs->stage_cap = 1024;
+  HIP_TRY(hipMalloc(&fs->d_stage, (size_t)fs->n_blocks * fs->stage_cap * sizeof(FillEntry)));
+  HIP_TRY(hipMalloc(&fs->d_stage_count, (size_t)fs->n_blocks * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&fs->d_cnt, (size_t)FILL_MAX_BATCH * fs->n_blocks * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&fs->d_totals, FILL_MAX_BATCH * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&fs->d_overflow, sizeof(int32_t)));
+  fp.stage = fs->d_stage;
+  fp.stage_cap = fs->stage_cap;
+  fp.stage_count = fs->d_stage_count;
+  fp.cnt = fs->d_cnt;
+  fp.overflow = fs->d_overflow;
+  fp.n_launches = 1;
   return DSIM_OK;
 }
 
@@ -2247,21 +2236,56 @@ extern "C" int dsim_fill_open(dsim_fill **out, int device, int64_t thread_begin,
   return DSIM_OK;
 }
 
+/* One batch of <= FILL_MAX_BATCH launches: three dispatches.  counts[l] = accepted candidates of launch l of the batch;
+ * their points go to d_out rows rows_before, rows_before + 1, ... in (launch, thread) order (rows >= capacity are dropped).
+ * *accepted = all accepted candidates of the batch.  A batch in which a workgroup ran out of staging rows is redone
+ * launch by launch from the RNG states it started with. */
+static int fill_batch(dsim_fill *fs, int n_launches, int64_t *counts, int64_t rows_before, int64_t capacity, int64_t *accepted) {
+  const int64_t n = fs->n_threads;
+  HIP_TRY(hipMemcpyAsync(fs->s0_keep, fs->s0, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, fs->stream));
+  HIP_TRY(hipMemcpyAsync(fs->s1_keep, fs->s1, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, fs->stream));
+  HIP_TRY(hipMemsetAsync(fs->d_overflow, 0, sizeof(int32_t), fs->stream));
+  fs->fp.n_launches = n_launches;
+  fill_batch_kernel<<<fs->n_blocks, 256, fs->lds, fs->stream>>>(fs->fp);
+  HIP_TRY(hipGetLastError());
+  fill_scan_kernel<<<n_launches, 256, 0, fs->stream>>>(fs->d_cnt, fs->n_blocks, fs->d_totals);
+  HIP_TRY(hipGetLastError());
+  fill_place_kernel<<<fs->n_blocks, 256, 0, fs->stream>>>(fs->d_stage, fs->d_stage_count, fs->stage_cap, fs->d_cnt, fs->d_totals, n_launches,
+                                                           rows_before, capacity, fs->d_out);
+  HIP_TRY(hipGetLastError());
+  int32_t overflow = 0;
+  HIP_TRY(hipMemcpyAsync(&overflow, fs->d_overflow, sizeof(int32_t), hipMemcpyDeviceToHost, fs->stream));
+  HIP_TRY(hipMemcpyAsync(counts, fs->d_totals, (size_t)n_launches * sizeof(int64_t), hipMemcpyDeviceToHost, fs->stream));
+  HIP_TRY(hipStreamSynchronize(fs->stream));
+  if (overflow) {
+    if (n_launches == 1) return fail(DSIM_ERR_STATE, "dsim_fill_mesh: a single launch overflowed its staging rows"); /* cannot happen: 256 <= stage_cap */
+    HIP_TRY(hipMemcpyAsync(fs->s0, fs->s0_keep, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, fs->stream));
+    HIP_TRY(hipMemcpyAsync(fs->s1, fs->s1_keep, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, fs->stream));
+    int64_t total = 0;
+    for (int l = 0; l < n_launches; l++) {
+      int64_t one = 0;
+      int rc = fill_batch(fs, 1, counts + l, rows_before + total, capacity, &one);
+      if (rc) return rc;
+      total += one;
+    }
+    *accepted = total;
+    return DSIM_OK;
+  }
+  int64_t total = 0;
+  for (int l = 0; l < n_launches; l++) total += counts[l];
+  *accepted = total;
+  return DSIM_OK;
+}
+
 /* n_launches more launches over the session's threads.  counts[l] = accepted candidates of launch l; their points,
  * in (launch, thread) order, go to points[(row, 3)] - at most `capacity` rows, the rest is dropped (the caller sizes
- * its batches so that nothing it needs is; *n_rows = rows written).  Accepted points are compacted ON THE DEVICE in
- * thread order (simulations.py:573-576 keeps the finite rows of every launch in order): flags -> exclusive scan ->
- * scatter behind the rows already there; only counts and rows cross PCIe, once per call. */
+ * its batches so that nothing it needs is; *n_rows = rows written).  The launches run in batches of up to 64 per dispatch
+ * (fill_batch); accepted points are put in order ON THE DEVICE (simulations.py:573-576 keeps the finite rows of every
+ * launch in thread order); only counts and rows cross PCIe, once per call. */
 extern "C" int dsim_fill_run(dsim_fill *fs, int64_t n_launches, int64_t *counts, double *points, int64_t capacity, int64_t *n_rows) {
   if (!fs || n_launches <= 0 || !counts || capacity < 0 || (capacity > 0 && !points)) return fail(DSIM_ERR_INVALID, "dsim_fill_run: bad arguments");
   HIP_TRY(hipSetDevice(fs->device));
   if (fs->launches + n_launches > 1000000) return fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
-  if (fs->counts_cap < n_launches) {
-    if (fs->d_counts) HIP_TRY(hipFree(fs->d_counts));
-    fs->d_counts = nullptr;
-    HIP_TRY(hipMalloc(&fs->d_counts, n_launches * sizeof(int64_t)));
-    fs->counts_cap = n_launches;
-  }
   const int64_t cap = std::max<int64_t>(capacity, 1);
   if (fs->out_cap < cap) {
     if (fs->d_out) HIP_TRY(hipFree(fs->d_out));
@@ -2269,22 +2293,15 @@ extern "C" int dsim_fill_run(dsim_fill *fs, int64_t n_launches, int64_t *counts,
     HIP_TRY(hipMalloc(&fs->d_out, (size_t)cap * 3 * sizeof(double)));
     fs->out_cap = cap;
   }
-  HIP_TRY(hipMemsetAsync(fs->d_have, 0, 2 * sizeof(int64_t), fs->stream));
-  const int64_t n = fs->n_threads;
-  const int grid = grid_for(n, 256);
-  for (int64_t k = 0; k < n_launches; k++) {
-    fill_mesh_kernel<<<grid, 256, fs->lds, fs->stream>>>(fs->fp);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(fs->d_tmp, fs->tmp_bytes, fs->d_flag, fs->d_pref, (int)n, fs->stream));
-    fill_scatter_kernel<<<grid, 256, 0, fs->stream>>>(fs->px, fs->py, fs->pz, fs->d_flag, fs->d_pref, n, capacity, fs->d_have + (k & 1),
-                                                      fs->d_have + ((k + 1) & 1), fs->d_counts + k, fs->d_out);
-    HIP_TRY(hipGetLastError());
+  int64_t have = 0;
+  for (int64_t k = 0; k < n_launches; k += FILL_MAX_BATCH) {
+    const int nl = (int)std::min<int64_t>(FILL_MAX_BATCH, n_launches - k);
+    int64_t got = 0;
+    int rc = fill_batch(fs, nl, counts + k, have, capacity, &got);
+    if (rc) return rc;
+    have += got;
   }
   fs->launches += n_launches;
-  int64_t have = 0;
-  HIP_TRY(hipMemcpyAsync(&have, fs->d_have + (n_launches & 1), sizeof(int64_t), hipMemcpyDeviceToHost, fs->stream));
-  HIP_TRY(hipMemcpyAsync(counts, fs->d_counts, n_launches * sizeof(int64_t), hipMemcpyDeviceToHost, fs->stream));
-  HIP_TRY(hipStreamSynchronize(fs->stream));
   const int64_t rows = std::min(have, capacity);
   if (rows > 0) {
     HIP_TRY(hipMemcpyAsync(points, fs->d_out, (size_t)rows * 3 * sizeof(double), hipMemcpyDeviceToHost, fs->stream));

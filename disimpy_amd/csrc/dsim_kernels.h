@@ -1198,15 +1198,27 @@ struct FillParams {
   const int2 *ment;
   const float4 *ment_yz;
   int64_t n_points;
-  double *px, *py, *pz; /* written where flag = 1 */
-  int32_t *flag;        /* 1 = the candidate of this thread was accepted in this launch */
   uint64_t *s0, *s1;
+  /* one dispatch = a BATCH of the reference's launches (fill_batch_kernel): */
+  int n_launches;          /* launches of the batch, <= FILL_MAX_BATCH */
+  int stage_cap;           /* accepted candidates a workgroup can park (FillEntry each) */
+  struct FillEntry *stage; /* [workgroups][stage_cap], in the order the workgroup's threads got there */
+  int32_t *stage_count;    /* [workgroups] entries parked */
+  int32_t *cnt;            /* [n_launches][workgroups] candidates accepted per launch and workgroup */
+  int32_t *overflow;       /* set when a workgroup ran out of parking room: the batch is void, the host redoes it */
   int intra;
   double voxel[3];
   MeshDev mesh;
 };
 
 #define FILL_MAX_HITS 1000
+#define FILL_MAX_BATCH 64
+
+/* an accepted candidate on its way to its row: key = launch << 8 | thread inside the workgroup */
+struct FillEntry {
+  double x, y, z;
+  uint32_t key, pad;
+};
 
 /* The reference's loop (simulations.py:461-492) over one column in its own order; returns the number of distinct
  * triangles met, or -1 when the sample is abandoned (:478-479: the 1000-slot list is full and another list entry
@@ -1239,23 +1251,12 @@ DSD int fill_count_reference_order(const FillParams &p, const V3 &pt, int llx, i
   return n_hits;
 }
 
-/* One candidate point per thread per launch (simulations.py:421-502, launched from :560-579 with a fresh all-inf
- * `points` array every time, so every thread draws in every launch). */
-__global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
-  extern __shared__ double lds[];
-  const int n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
-  for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) lds[i] = p.mesh.bounds[i];
-  __syncthreads();
-  const double *xs = lds, *ys = lds + p.mesh.nx + 1, *zs = lds + p.mesh.nx + p.mesh.ny + 2;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= p.n_points) return;
-  Rng rng = {p.s0[tid], p.s1[tid]};
-  V3 pt;
+/* One candidate point of one thread in one launch of the reference (simulations.py:421-502): three uniforms, the
+ * +x ray's triangle count, accepted when the parity says inside (intra) / outside.  Advances the thread's RNG state. */
+DSD bool fill_candidate(const FillParams &p, const double *xs, const double *ys, const double *zs, Rng &rng, V3 &pt) {
   pt.x = rng_uniform_f64(rng) * p.voxel[0];
   pt.y = rng_uniform_f64(rng) * p.voxel[1];
   pt.z = rng_uniform_f64(rng) * p.voxel[2];
-  p.s0[tid] = rng.s0;
-  p.s1[tid] = rng.s1;
   const V3 ray = {1.0, 0.0, 0.0};
   const MeshDev &ms = p.mesh;
   /* non-periodic lookups (:455-460): ll on min(p, p+ray) = p, ul on max = p+ray */
@@ -1295,12 +1296,122 @@ __global__ __launch_bounds__(256) void fill_mesh_kernel(const FillParams p) {
   }
   if (n_hits >= FILL_MAX_HITS) n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, uly, llz, ulz);
   const bool inside = (n_hits & 1) == 1;
-  const bool accept = n_hits >= 0 && (p.intra ? inside : !inside);
-  p.flag[tid] = accept ? 1 : 0;
-  if (accept) {
-    p.px[tid] = pt.x;
-    p.py[tid] = pt.y;
-    p.pz[tid] = pt.z;
+  return n_hits >= 0 && (p.intra ? inside : !inside);
+}
+
+/* A BATCH of the reference's launches in one dispatch.  The reference launches _cuda_fill_mesh again and again - every
+ * thread draws one candidate per launch from its own RNG state (simulations.py:560-579, a fresh all-inf `points` array
+ * each time) - and appends the accepted points of a launch in thread order.  Thread t only ever needs state t, so it
+ * can run its part of `n_launches` launches back to back with the state in registers (round 3: one dispatch per launch
+ * that read and wrote 32 bytes of state per thread, then a library scan and a scatter - 16 000 dispatches for 1e7
+ * points inside the neuron).  An accepted candidate is parked in the workgroup's own staging rows with its (launch,
+ * thread) key; fill_scan_kernel and fill_place_kernel then put the batch in (launch, thread) order - the order the
+ * reference's appends produce. */
+__global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p) {
+  extern __shared__ double lds[];
+  __shared__ int s_parked, s_cnt[FILL_MAX_BATCH];
+  const int n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
+  for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) lds[i] = p.mesh.bounds[i];
+  if (threadIdx.x < FILL_MAX_BATCH) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_parked = 0;
+  __syncthreads();
+  const double *xs = lds, *ys = lds + p.mesh.nx + 1, *zs = lds + p.mesh.nx + p.mesh.ny + 2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < p.n_points) {
+    Rng rng = {p.s0[tid], p.s1[tid]};
+    FillEntry *stage = p.stage + (int64_t)blockIdx.x * p.stage_cap;
+    for (int l = 0; l < p.n_launches; l++) {
+      V3 pt;
+      if (!fill_candidate(p, xs, ys, zs, rng, pt)) continue;
+      atomicAdd(&s_cnt[l], 1);
+      const int slot = atomicAdd(&s_parked, 1);
+      if (slot < p.stage_cap) {
+        FillEntry e = {pt.x, pt.y, pt.z, ((uint32_t)l << 8) | threadIdx.x, 0u};
+        stage[slot] = e;
+      } else {
+        *p.overflow = 1;
+      }
+    }
+    p.s0[tid] = rng.s0;
+    p.s1[tid] = rng.s1;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < p.n_launches) p.cnt[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+  if (threadIdx.x == 0) p.stage_count[blockIdx.x] = min(s_parked, p.stage_cap);
+}
+
+/* workgroup l: exclusive prefix sum of cnt[l][0 .. n_blocks) in place (what the workgroups before b accepted in launch
+ * l) and the launch's total; one workgroup of 256 threads walks the row in tiles of 4096 (as sort_scan_kernel does) */
+__global__ __launch_bounds__(256) void fill_scan_kernel(int32_t *cnt, int n_blocks, int64_t *totals) {
+  __shared__ uint32_t wsum[4];
+  int32_t *row = cnt + (int64_t)blockIdx.x * n_blocks;
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint32_t carry = 0;
+  for (int base = 0; base < n_blocks; base += 16 * 256) {
+    const int b0 = base + 16 * t;
+    uint32_t v[16], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      v[q] = b0 + q < n_blocks ? (uint32_t)row[b0 + q] : 0u;
+      mine += v[q];
+    }
+    const uint32_t incl = (uint32_t)wave_inclusive_sum((int)mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t sw = wsum[w];
+      total += sw;
+      if (w < wave) before += sw;
+    }
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      if (b0 + q < n_blocks) row[b0 + q] = (int32_t)run;
+      run += v[q];
+    }
+    carry += total;
+    __syncthreads();
+  }
+  if (t == 0) totals[blockIdx.x] = (int64_t)carry;
+}
+
+/* workgroup b: its parked candidates go to their rows.  Row of the candidate of thread t in launch l =
+ * rows before the batch + what launches < l accepted + what the workgroups before b accepted in launch l (pref) + the
+ * accepted threads below t in this workgroup and launch (a 256-bit map per launch in LDS).  Rows >= capacity are
+ * dropped (the caller sizes its batches so that none it needs is). */
+__global__ __launch_bounds__(256) void fill_place_kernel(const FillEntry *stage, const int32_t *stage_count, int stage_cap, const int32_t *pref,
+                                                         const int64_t *totals, int n_launches, int64_t rows_before, int64_t capacity,
+                                                         double *out) {
+  __shared__ unsigned long long bits[FILL_MAX_BATCH][4];
+  __shared__ long long base[FILL_MAX_BATCH];
+  const int t = (int)threadIdx.x;
+  if (t < FILL_MAX_BATCH) bits[t][0] = bits[t][1] = bits[t][2] = bits[t][3] = 0ULL;
+  if (t < n_launches) {
+    long long before = rows_before;
+    for (int l = 0; l < t; l++) before += totals[l];
+    base[t] = before + pref[(int64_t)t * gridDim.x + blockIdx.x];
+  }
+  __syncthreads();
+  const int n_e = stage_count[blockIdx.x];
+  const FillEntry *mine = stage + (int64_t)blockIdx.x * stage_cap;
+  for (int e = t; e < n_e; e += 256) {
+    const uint32_t key = mine[e].key;
+    atomicOr(&bits[key >> 8][(key & 255u) >> 6], 1ULL << (key & 63u));
+  }
+  __syncthreads();
+  for (int e = t; e < n_e; e += 256) {
+    const FillEntry en = mine[e];
+    const int l = (int)(en.key >> 8), th = (int)(en.key & 255u), w = th >> 6;
+    int rank = __popcll(bits[l][w] & ((1ULL << (th & 63)) - 1ULL));
+    for (int q = 0; q < w; q++) rank += __popcll(bits[l][q]);
+    const long long row = base[l] + rank;
+    if (row < capacity) {
+      out[row * 3] = en.x;
+      out[row * 3 + 1] = en.y;
+      out[row * 3 + 2] = en.z;
+    }
   }
 }
 

@@ -505,45 +505,63 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const int lcs = 3 * lk + 2;                 /* log2 of the cell slots per subvoxel, lk > 0 */
     const unsigned cmask = (1u << lcs) - 1u;
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
-    int cursor = 0;
+    /* two cursors: over the 64 first-run slots and over the named extra runs behind them.  A trip of stage 1c gives
+     * every lane one of each - the extras are few (a box that straddles a subvoxel face: one walker in ten), so a trip
+     * of their own would run at a tenth of its width; riding along, they cost the decoding of their names in a trip
+     * that has to run anyway */
+    int cur_a = 0, cur_b = 0;
+    const int n_extra = n_runq - 64;
     int n_items = 0;        /* items waiting in the queue (wave-uniform) */
     int n_surv = 0;         /* survivors waiting in the pool (wave-uniform) */
     bool drain_all = false; /* the next run does not fit behind the waiting items */
-    while (cursor < n_runq) {
-      /* -- 1c: up to 64 runs per round, one per lane */
-      while (cursor < n_runq && n_items <= COOP_ITEM_CAP - 64) {
-        const int idx = cursor + lane;
-        uint2 e = make_uint2(0xffffffffu, 0u);
-        if (idx < 64) {
-          e = W->first[idx];
-        } else if (idx < n_runq) {
-          const unsigned m = W->more[idx - 64];
+    /* records of a run: {first record, number of records} */
+    auto look_up = [&](const uint2 &e) -> int2 {
+      int first = 0, cnt = 0;
+      if (e.x != 0xffffffffu) {
+        STAT_LANE(5);
+        STAT_WAVE(5);
+        int cell = (int)e.y;
+        bool some = true;
+        if (lk > 0) {
+          const int base = ms.sv_base[e.y >> lcs];
+          some = base >= 0;
+          cell = base + (int)(e.y & cmask);
+        }
+        if (some && !ABLATE(2)) {
+          const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
+          first = (int)r0i;
+          cnt = (int)(r1i - r0i);
+        }
+      }
+      return make_int2(first, cnt);
+    };
+    /* the records of a run as items of four; the last one holds what is left (its count goes in after the loop: the loop
+     * itself is one store and two additions per item - its trip count is the longest run of the 64) */
+    auto write_items = [&](uint2 *q, int first, int cnt, int nb, unsigned tag) {
+      unsigned x = (unsigned)first | (3u << 30);
+      for (uint2 *const end = q + nb - 1; q < end; q++, x += 4u) *q = make_uint2(x, tag);
+      *q = make_uint2((x & 0x3fffffffu) | ((unsigned)(cnt - 4 * (nb - 1) - 1) << 30), tag);
+    };
+    while (cur_a < 64 || cur_b < n_extra) {
+      /* -- 1c: up to 64 first runs and 64 extra runs per trip, one of each per lane */
+      while ((cur_a < 64 || cur_b < n_extra) && n_items <= COOP_ITEM_CAP - 64) {
+        uint2 ea = make_uint2(0xffffffffu, 0u), eb = make_uint2(0xffffffffu, 0u);
+        if (cur_a + lane < 64) ea = W->first[cur_a + lane];
+        const bool extras = cur_b < n_extra; /* wave-uniform */
+        if (extras && cur_b + lane < n_extra) {
+          const unsigned m = W->more[cur_b + lane];
           if (m != 0xffffffffu) {
             const int o = (int)(m & 63u);
             const int4 pa = W->plan_a[o];
             const int2 pb = W->plan_b[o];
             const RunPlan q = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y & 255, (pb.y >> 8) & 255, (pb.y >> 16) & 255, (pb.y >> 24) & 255};
-            e = make_run(ms, o, q, (int)(m >> 6));
+            eb = make_run(ms, o, q, (int)(m >> 6));
           }
         }
-        int first = 0, cnt = 0;
-        if (e.x != 0xffffffffu) {
-          STAT_LANE(5);
-          STAT_WAVE(5);
-          int cell = (int)e.y;
-          bool some = true;
-          if (lk > 0) {
-            const int base = ms.sv_base[e.y >> lcs];
-            some = base >= 0;
-            cell = base + (int)(e.y & cmask);
-          }
-          if (some && !ABLATE(2)) {
-            const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
-            first = (int)r0i;
-            cnt = (int)(r1i - r0i);
-          }
-        }
-        const int nb = (cnt + 3) >> 2;
+        const int2 ra = look_up(ea);
+        int2 rb = make_int2(0, 0);
+        if (extras) rb = look_up(eb);
+        const int nba = (ra.y + 3) >> 2, nbb = (rb.y + 3) >> 2, nb = nba + nbb;
         if (nb > 0) {
           STAT_LANE(3);
           STAT_WAVE(3);
@@ -556,29 +574,30 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             drain_all = true;
             break;
           }
-          /* a single run with more records than the whole queue holds: its owner works serially */
-          if (lane == 0) W->overflow[(int)(e.x & 63u)] = 1;
-          cursor += 1;
+          /* the runs of lane 0 alone hold more records than the whole queue: their owners work serially */
+          if (lane == 0) {
+            if (ea.x != 0xffffffffu) W->overflow[(int)(ea.x & 63u)] = 1;
+            if (eb.x != 0xffffffffu) W->overflow[(int)(eb.x & 63u)] = 1;
+          }
+          cur_a = min(64, cur_a + 1);
+          cur_b = min(n_extra, cur_b + 1);
           continue;
         }
-        if (lane < n_take && nb > 0) {
-          /* items of four records; the last one holds what is left (its count goes in after the loop: the loop itself is
-           * one store and two additions per item - its trip count is the longest run of the 64) */
-          const unsigned tag = e.x & 0xffffffu;
+        if (lane < n_take) {
           uint2 *q = &W->items[n_items + incl - nb];
-          unsigned x = (unsigned)first | (3u << 30);
-          for (uint2 *const end = q + nb - 1; q < end; q++, x += 4u) *q = make_uint2(x, tag);
-          *q = make_uint2((x & 0x3fffffffu) | ((unsigned)(cnt - 4 * (nb - 1) - 1) << 30), tag);
+          if (nba > 0) write_items(q, ra.x, ra.y, nba, ea.x & 0xffffffu);
+          if (nbb > 0) write_items(q + nba, rb.x, rb.y, nbb, eb.x & 0xffffffu);
         }
         n_items += __builtin_amdgcn_readlane(incl, n_take - 1);
-        cursor += n_take;
+        cur_a = min(64, cur_a + n_take);
+        cur_b = min(n_extra, cur_b + n_take);
         if (n_take < 64) break;
       }
       T_MARK(W, lane, 13);
       /* -- 2: all lanes drain the item queue: float32 AABB + plane culling against the owner's box.
        * While more runs are coming only full trips of 64 items are drained (the tail of the queue);
        * the remainder waits at the head for the next round */
-      const int start = (cursor >= n_runq || drain_all) ? 0 : (n_items & 63);
+      const int start = ((cur_a >= 64 && cur_b >= n_extra) || drain_all) ? 0 : (n_items & 63);
       drain_all = false;
       if (start == n_items) continue;
       wave_sync();

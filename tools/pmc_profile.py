@@ -25,6 +25,10 @@ PASSES = {
           "SQ_ACTIVE_INST_ANY",
     "mem": "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT "
            "TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE",
+    # LDS: cycles the LDS array was busy and how many of them were bank-conflict replays (MI355X_MICROARCH.md, LDS:
+    # SQ_LDS_BANK_CONFLICT = extra cycles, SQ_LDS_IDX_ACTIVE = all LDS-array cycles)
+    "lds": "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INSTS_LDS "
+           "SQ_WAVE_CYCLES",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
 }
@@ -57,7 +61,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
     ap.add_argument("--walkers", type=int, default=1_000_000)
-    ap.add_argument("--tag", default="r03")
+    ap.add_argument("--tag", default="r04")
     ap.add_argument("--match", default="walk_kernel")
     ap.add_argument("--passes", default="sq,mem,fetch,write")
     ap.add_argument("--bench-args", default="")
@@ -112,6 +116,11 @@ def main():
         entry["l2_read_req_per_wave_step"] = m["TCP_TCC_READ_REQ_sum"] / ws
         if "sq" in raw:  # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
             entry["valu_busy"] = raw["sq"]["counters"]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (m["GRBM_GUI_ACTIVE"] / 8)
+    if "lds" in raw:
+        c = raw["lds"]["counters"]
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            entry["lds_bank_conflict_frac_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+            entry["lds_array_busy_frac_of_wave_cycles"] = c["SQ_LDS_IDX_ACTIVE"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
     if "fetch" in raw and "write" in raw:
         nl = max(1, raw["fetch"]["dispatches"])
         rd = raw["fetch"]["counters"]["FETCH_SIZE"] * 1024 * 2  # KB; gfx950: FETCH_SIZE reports half the bytes
