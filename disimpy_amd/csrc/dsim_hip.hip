@@ -850,6 +850,8 @@ static int ensure_sort_buffers(dsim_sim *h) {
   /* 64^3 bins of the periodic voxel; measured on C5b at 1e7 walkers: 32^3 ... 256^3 bins give the same walk-kernel rate
    * (1.24e10 +- 0.3 %) - what matters is that a wavefront's walkers share a neighbourhood, not their order inside it -
    * and the single-workgroup scan of 2^24 bins costs 3.5 ms (DSIM_SORT_BITS: tuning runs) */
+  /* [r4] re-measured with the overlapping cells: 21 bits gain 0.2 % for M = 1 (A/B) and cost a small shard's recorded mode,
+   * which sorts at every launch, 9 % (the 3.6 ms scan of 2^21 bins): profiles/history/r04_sweeps_xcd_run_sort_bits_groups.txt */
   h->sort_bits = 18;
   if (const char *e = getenv("DSIM_SORT_BITS")) {
     const int v = atoi(e);

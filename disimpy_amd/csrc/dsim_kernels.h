@@ -268,7 +268,10 @@ struct BestHit {
  * VALU instructions in a VALU-bound kernel: round 2 shipped with 124 spilled SGPRs).  With KA = 1 the kernel instead
  * re-reads what a stage needs from the kernarg segment (scalar loads out of the constant cache) through a pointer the
  * compiler cannot see through, so no value lives longer than the stage that uses it.  KA = 0 (every other kernel, and
- * the test wrappers): the by-value parameter as it is.  WalkParams must be the kernel's first and only argument. */
+ * the test wrappers): the by-value parameter as it is.  WalkParams must be the kernel's first and only argument and
+ * trivially copyable (asserted here; dsu_kernarg_check in the unit library compares the segment with the parameter
+ * dword by dword on the device: tests/test_gpu_device_units.py). */
+static_assert(__is_trivially_copyable(WalkParams), "fresh_params reads WalkParams straight out of the kernarg segment");
 template <int KA>
 DSD const WalkParams &fresh_params(const WalkParams &p) {
   if (KA) {
@@ -1251,87 +1254,157 @@ DSD int fill_count_reference_order(const FillParams &p, const V3 &pt, int llx, i
   return n_hits;
 }
 
-/* One candidate point of one thread in one launch of the reference (simulations.py:421-502): three uniforms, the
- * +x ray's triangle count, accepted when the parity says inside (intra) / outside.  Advances the thread's RNG state. */
-DSD bool fill_candidate(const FillParams &p, const double *xs, const double *ys, const double *zs, Rng &rng, V3 &pt) {
-  pt.x = rng_uniform_f64(rng) * p.voxel[0];
-  pt.y = rng_uniform_f64(rng) * p.voxel[1];
-  pt.z = rng_uniform_f64(rng) * p.voxel[2];
-  const V3 ray = {1.0, 0.0, 0.0};
+/* The triangles a +x ray from pt meets in the bucket of its (y, z) column (FillParams::mcol): the number of distinct
+ * ones, FILL_MAX_HITS or more when the reference's give-up rule (simulations.py:478-479) has to decide */
+DSD int fill_count_bucket(const FillParams &p, const double *ys, const double *zs, const V3 &pt, int col, int lly, int llz, int llx, int ulx) {
   const MeshDev &ms = p.mesh;
-  /* non-periodic lookups (:455-460): ll on min(p, p+ray) = p, ul on max = p+ray */
-  const int llx = ll_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x);
-  const int lly = ll_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
-  const int llz = ll_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
-  const int ulx = ul_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x + ray.x);
-  const int uly = ul_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
-  const int ulz = ul_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
-  /* The y and z ranges of a +x ray hold ONE subvoxel each, or none when the point sits exactly on a boundary
-   * (ul <= ll + 1 for a degenerate interval): one column of the index, or no triangle at all. */
+  const V3 ray = {1.0, 0.0, 0.0};
+  const int2 mc = p.mcol[col];
+  const int G = mc.y;
+  int iy = (int)((pt.y - ys[lly]) * ((double)G * ms.inv_hy)), iz = (int)((pt.z - zs[llz]) * ((double)G * ms.inv_hz));
+  iy = min(max(iy, 0), G - 1), iz = min(max(iz, 0), G - 1);
+  const int b = mc.x + iy * G + iz;
+  const float fy = (float)pt.y, fz = (float)pt.z;
+  const int end = p.mstart[b + 1];
   int n_hits = 0;
-  if (uly - lly == 1 && ulz - llz == 1) {
-    const int2 mc = p.mcol[lly * ms.nz + llz];
-    if (mc.x >= 0) {
-      const int G = mc.y;
-      int iy = (int)((pt.y - ys[lly]) * ((double)G * ms.inv_hy)), iz = (int)((pt.z - zs[llz]) * ((double)G * ms.inv_hz));
-      iy = min(max(iy, 0), G - 1), iz = min(max(iz, 0), G - 1);
-      const int b = mc.x + iy * G + iz;
-      const float fy = (float)pt.y, fz = (float)pt.z;
-      const int end = p.mstart[b + 1];
-      for (int i = p.mstart[b]; i < end; i++) {
-        const int2 en = p.ment[i];
-        const int x = en.y >> 16, prev = (en.y & 0xffff) - 1;
-        if (x < llx) break; /* descending x: the rest of the bucket lies behind the point */
-        if (x >= ulx) continue;
-        const float4 yz = p.ment_yz[i];
-        if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
-        if (prev >= llx) continue; /* the same triangle is listed at a nearer x of this ray as well: counted there */
-        const double *rec = ms.tri + (int64_t)en.x * DS_TRI_STRIDE;
-        double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
-        if (d > 0) n_hits++;
-      }
-    }
-  } else if (uly > lly && ulz > llz) {
-    n_hits = FILL_MAX_HITS; /* cannot happen (see above); the reference's loop decides */
+  for (int i = p.mstart[b]; i < end; i++) {
+    const int2 en = p.ment[i];
+    const int x = en.y >> 16, prev = (en.y & 0xffff) - 1;
+    if (x < llx) break; /* descending x: the rest of the bucket lies behind the point */
+    if (x >= ulx) continue;
+    const float4 yz = p.ment_yz[i];
+    if (fy < yz.x || fy > yz.z || fz < yz.y || fz > yz.w) continue;
+    if (prev >= llx) continue; /* the same triangle is listed at a nearer x of this ray as well: counted there */
+    const double *rec = ms.tri + (int64_t)en.x * DS_TRI_STRIDE;
+    double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), pt, ray);
+    if (d > 0) n_hits++;
   }
-  if (n_hits >= FILL_MAX_HITS) n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, uly, llz, ulz);
-  const bool inside = (n_hits & 1) == 1;
-  return n_hits >= 0 && (p.intra ? inside : !inside);
+  return n_hits;
 }
+
+/* the launch parameters of the fill kernel read afresh from the kernarg segment (see fresh_params: FillParams is the
+ * kernel's first and only argument) */
+DSD const FillParams &fresh_fill(const FillParams &p) {
+  auto k = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  (void)p;
+  return *(const FillParams *)k;
+}
+
+/* candidates that have a bucket to walk, waiting for a full trip of the wavefront (fill_batch_kernel) */
+#define FILL_QUEUE_CAP 128
+struct FillQueue {
+  double x[FILL_QUEUE_CAP], y[FILL_QUEUE_CAP], z[FILL_QUEUE_CAP];
+  uint32_t key[FILL_QUEUE_CAP]; /* launch << 8 | thread inside the workgroup */
+  int32_t llx[FILL_QUEUE_CAP], ulx[FILL_QUEUE_CAP], col[FILL_QUEUE_CAP]; /* col = lly << 16 | llz */
+};
 
 /* A BATCH of the reference's launches in one dispatch.  The reference launches _cuda_fill_mesh again and again - every
  * thread draws one candidate per launch from its own RNG state (simulations.py:560-579, a fresh all-inf `points` array
  * each time) - and appends the accepted points of a launch in thread order.  Thread t only ever needs state t, so it
- * can run its part of `n_launches` launches back to back with the state in registers (round 3: one dispatch per launch
+ * runs its part of `n_launches` launches back to back with the state in registers (round 3: one dispatch per launch
  * that read and wrote 32 bytes of state per thread, then a library scan and a scatter - 16 000 dispatches for 1e7
- * points inside the neuron).  An accepted candidate is parked in the workgroup's own staging rows with its (launch,
- * thread) key; fill_scan_kernel and fill_place_kernel then put the batch in (launch, thread) order - the order the
- * reference's appends produce. */
-__global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p) {
+ * points inside the neuron).
+ *
+ * Most candidates are decided at once - their (y, z) column of the index holds no triangle at all (the neuron fills
+ * 0.025 % of its voxel) - while one in a few has a bucket of triangles to walk, a loop of dependent look-ups whose
+ * length differs from lane to lane.  Left in place that loop runs on nearly every launch for the few lanes that need
+ * it; here those candidates are QUEUED per wavefront (point, key, x range, column: 40 bytes in LDS, slots from a
+ * ballot) and walked 64 at a time, whoever drew them.  An accepted candidate is parked in the workgroup's staging rows
+ * with its (launch, thread) key; fill_scan_kernel and fill_place_kernel then put the batch in (launch, thread) order -
+ * the order the reference's appends produce.  Candidates, counts and order are the reference's bit for bit
+ * (tests/test_gpu_parity.py, test_fill_mesh_identical_to_oracle; two ranks: tests/test_gpu_two_ranks.py). */
+__global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p_arg) {
   extern __shared__ double lds[];
   __shared__ int s_parked, s_cnt[FILL_MAX_BATCH];
-  const int n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
-  for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) lds[i] = p.mesh.bounds[i];
+  __shared__ FillQueue s_queue[4];
+  const FillParams &p = fresh_fill(p_arg);
+  const MeshDev &ms = p.mesh;
+  const int n_bounds = ms.nx + ms.ny + ms.nz + 3;
+  for (int i = threadIdx.x; i < n_bounds; i += blockDim.x) lds[i] = ms.bounds[i];
   if (threadIdx.x < FILL_MAX_BATCH) s_cnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_parked = 0;
   __syncthreads();
-  const double *xs = lds, *ys = lds + p.mesh.nx + 1, *zs = lds + p.mesh.nx + p.mesh.ny + 2;
+  const double *xs = lds, *ys = lds + ms.nx + 1, *zs = lds + ms.nx + ms.ny + 2;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid < p.n_points) {
-    Rng rng = {p.s0[tid], p.s1[tid]};
-    FillEntry *stage = p.stage + (int64_t)blockIdx.x * p.stage_cap;
-    for (int l = 0; l < p.n_launches; l++) {
-      V3 pt;
-      if (!fill_candidate(p, xs, ys, zs, rng, pt)) continue;
-      atomicAdd(&s_cnt[l], 1);
-      const int slot = atomicAdd(&s_parked, 1);
-      if (slot < p.stage_cap) {
-        FillEntry e = {pt.x, pt.y, pt.z, ((uint32_t)l << 8) | threadIdx.x, 0u};
-        stage[slot] = e;
-      } else {
-        *p.overflow = 1;
+  const bool live = tid < p.n_points;
+  const int lane = (int)(threadIdx.x & 63);
+  FillQueue &Q = s_queue[threadIdx.x >> 6];
+  FillEntry *stage = p.stage + (int64_t)blockIdx.x * p.stage_cap;
+  Rng rng = {1, 1};
+  if (live) rng.s0 = p.s0[tid], rng.s1 = p.s1[tid];
+  auto park = [&](const V3 &pt, uint32_t key) {
+    atomicAdd(&s_cnt[key >> 8], 1);
+    const int slot = atomicAdd(&s_parked, 1);
+    if (slot < p.stage_cap) {
+      FillEntry e = {pt.x, pt.y, pt.z, key, 0u};
+      stage[slot] = e;
+    } else {
+      *p.overflow = 1;
+    }
+  };
+  /* one trip over the queued candidates [base, base + count), count <= 64: every lane walks one bucket */
+  auto walk_trip = [&](int base, int count) {
+    if (lane < count) {
+      const int q = base + lane;
+      const V3 pt = {Q.x[q], Q.y[q], Q.z[q]};
+      const FillParams &p = fresh_fill(p_arg);
+      const int lly = Q.col[q] >> 16, llz = Q.col[q] & 0xffff, llx = Q.llx[q], ulx = Q.ulx[q];
+      int n_hits = fill_count_bucket(p, ys, zs, pt, lly * p.mesh.nz + llz, lly, llz, llx, ulx);
+      if (n_hits >= FILL_MAX_HITS) n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, lly + 1, llz, llz + 1);
+      const bool inside = (n_hits & 1) == 1;
+      if (n_hits >= 0 && (p.intra ? inside : !inside)) park(pt, Q.key[q]);
+    }
+  };
+  int n_q = 0; /* candidates waiting in the queue (wave-uniform) */
+  for (int l = 0; l < fresh_fill(p_arg).n_launches; l++) {
+    const FillParams &p = fresh_fill(p_arg); /* re-read per launch: ~70 dwords of parameters do not stay in SGPRs */
+    const MeshDev &ms = p.mesh;
+    bool need = false, accept = false;
+    V3 pt = {0, 0, 0};
+    int llx = 0, ulx = 0, col = 0;
+    if (live) {
+      pt.x = rng_uniform_f64(rng) * p.voxel[0];
+      pt.y = rng_uniform_f64(rng) * p.voxel[1];
+      pt.z = rng_uniform_f64(rng) * p.voxel[2];
+      /* non-periodic lookups (:455-460): ll on min(p, p+ray) = p, ul on max = p+ray (ray = +x) */
+      llx = ll_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x);
+      const int lly = ll_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
+      const int llz = ll_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+      ulx = ul_subvoxel_overlap(xs, ms.nx, ms.inv_hx, pt.x + 1.0);
+      const int uly = ul_subvoxel_overlap(ys, ms.ny, ms.inv_hy, pt.y);
+      const int ulz = ul_subvoxel_overlap(zs, ms.nz, ms.inv_hz, pt.z);
+      /* The y and z ranges of a +x ray hold ONE subvoxel each, or none when the point sits exactly on a boundary
+       * (ul <= ll + 1 for a degenerate interval): one column of the index, or no triangle at all. */
+      int n_hits = 0;
+      if (uly - lly == 1 && ulz - llz == 1) {
+        col = (lly << 16) | llz; /* n_sv <= 4096 per axis */
+        need = p.mcol[lly * ms.nz + llz].x >= 0; /* the column holds triangles: its bucket is walked with the next full trip */
+      } else if (uly > lly && ulz > llz) {
+        n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, uly, llz, ulz); /* cannot happen (see above); the reference's loop decides */
+      }
+      if (!need) accept = n_hits >= 0 && (p.intra ? (n_hits & 1) == 1 : (n_hits & 1) == 0);
+    }
+    if (accept) park(pt, ((uint32_t)l << 8) | threadIdx.x);
+    const unsigned long long m = __ballot(need);
+    if (m != 0ULL) {
+      if (need) {
+        const int q = n_q + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        Q.x[q] = pt.x, Q.y[q] = pt.y, Q.z[q] = pt.z;
+        Q.key[q] = ((uint32_t)l << 8) | threadIdx.x;
+        Q.llx[q] = llx, Q.ulx[q] = ulx, Q.col[q] = col;
+      }
+      n_q += (int)__popcll(m);
+      wave_sync();
+      if (n_q >= 64) {
+        n_q -= 64;
+        walk_trip(n_q, 64);
+        wave_sync(); /* the trip's slots may be written again by the next launch */
       }
     }
+  }
+  if (n_q > 0) walk_trip(0, n_q);
+  if (live) {
     p.s0[tid] = rng.s0;
     p.s1[tid] = rng.s1;
   }

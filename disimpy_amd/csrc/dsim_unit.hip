@@ -250,6 +250,33 @@ __global__ __launch_bounds__(256) void mesh_pass_kernel(const WalkParams p, cons
   }
 }
 
+/* fresh_params<1> takes the kernarg segment for the kernel's WalkParams (nothing enforced that it is the
+ * first and only argument at offset 0).  This kernel has exactly that signature; it compares the two dword by dword
+ * and reports through p.exc. */
+__global__ void kernarg_check_kernel(const WalkParams p) {
+  const WalkParams &f = fresh_params<1>(p);
+  const uint32_t *a = reinterpret_cast<const uint32_t *>(&f);
+  uint32_t diff = 0;
+  WalkParams copy = p;
+  const uint32_t *b = reinterpret_cast<const uint32_t *>(&copy);
+  for (size_t i = 0; i < sizeof(WalkParams) / 4; i++) diff |= a[i] ^ b[i];
+  p.exc[0] = diff == 0 ? 1 : 2;
+}
+
+extern "C" int dsu_kernarg_check(void) {
+  WalkParams p;
+  uint8_t *bytes = reinterpret_cast<uint8_t *>(&p);
+  for (size_t i = 0; i < sizeof(WalkParams); i++) bytes[i] = (uint8_t)(i * 37u + 11u); /* every field a pattern of its own */
+  uint8_t *out = nullptr;
+  if (hipMalloc(&out, 1) != hipSuccess || hipMemset(out, 0, 1) != hipSuccess) return -1;
+  p.exc = out;
+  kernarg_check_kernel<<<1, 1>>>(p);
+  uint8_t got = 0;
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&got, out, 1, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(out);
+  return ok && got == 1 ? 0 : -1;
+}
+
 /* index_step_l: the step length the mesh index is laid out for (cell sizes; as dsim_create's step_l).  Returns 0 or -1. */
 extern "C" int dsu_mesh_pass(const double *vertices, long long n_vertices, const int64_t *faces, long long n_faces, const double *xs,
                              const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,

@@ -288,3 +288,14 @@ def test_subvoxel_lookups_reproduce_the_reference_scans(dev, host):
     npt.assert_array_equal(g.T, [[2, 4], [2, 4], [0, 1], [9, 10], [3, 3], [3, 4]])
     g = dev(9, [np.array([-0.05, 0.95, 2.31, -1.25]), np.array([0.05, 1.05, 2.32, -1.15])], 2, xs)
     npt.assert_array_equal(g.T, [[-1, 1], [9, 11], [23, 24], [-13, -11]])
+
+
+def test_kernel_parameters_read_from_the_kernarg_segment_are_the_parameters(dev):
+    """fresh_params<1> (csrc/dsim_kernels.h) re-reads WalkParams from the kernarg segment instead of keeping ~100 dwords in
+    SGPRs; that is only right while the struct is the kernel's first and only argument.  The unit
+    library launches a kernel of that signature with every byte of the struct patterned and compares on the device."""
+    import ctypes as C
+    import os
+
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "disimpy_amd", "csrc", "libdsim_unit.so"))
+    assert lib.dsu_kernarg_check() == 0
