@@ -1313,7 +1313,7 @@ struct FillQueue {
  * ballot) and walked 64 at a time, whoever drew them.  An accepted candidate is parked in the workgroup's staging rows
  * with its (launch, thread) key; fill_scan_kernel and fill_place_kernel then put the batch in (launch, thread) order -
  * the order the reference's appends produce.  Candidates, counts and order are the reference's bit for bit
- * (tests/test_gpu_parity.py, test_fill_mesh_identical_to_oracle; two ranks: tests/test_gpu_two_ranks.py). */
+ * (tests/test_gpu_parity.py, the fill tests; two ranks: tests/test_gpu_two_ranks.py). */
 __global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p_arg) {
   extern __shared__ double lds[];
   __shared__ int s_parked, s_cnt[FILL_MAX_BATCH];
