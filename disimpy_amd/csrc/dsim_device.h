@@ -135,14 +135,14 @@ DSD double line_circle_intersection(double r0, double r1, double s0, double s1, 
   double A = __builtin_fma(s0, s0, s1 * s1);
   double B = 2 * __builtin_fma(r0, s0, r1 * s1);
   double C = __builtin_fma(-radius, radius, __builtin_fma(r0, r0, r1 * r1));
-  return (-B + __builtin_sqrt(__builtin_fma(B, B, -(4 * A * C)))) / (2 * A);
+  return (-B + ds_sqrt_dev(__builtin_fma(B, B, -(4 * A * C)))) / (2 * A);
 }
 
 /* simulations.py:185-202 */
 DSD double line_sphere_intersection(const V3 &r0, const V3 &step, double radius) {
   double dp = dot3(step, r0);
   double inner = __builtin_fma(-radius, radius, dot3(r0, r0));
-  return -dp + __builtin_sqrt(__builtin_fma(dp, dp, -inner));
+  return -dp + ds_sqrt_dev(__builtin_fma(dp, dp, -inner)); /* correctly rounded, as the IEEE sqrt it replaces (ds_sqrt_dev) */
 }
 
 /* simulations.py:205-231 */
@@ -153,7 +153,7 @@ DSD double line_ellipsoid_intersection(const V3 &r0, const V3 &step, double a, d
   double B = 2 * __builtin_fma(ic * step.z, r0.z, __builtin_fma(ia * step.x, r0.x, ib * step.y * r0.y));
   double ra = r0.x / a, rb = r0.y / b, rc = r0.z / c;
   double C = __builtin_fma(rc, rc, __builtin_fma(ra, ra, rb * rb)) - 1;
-  return (-B + __builtin_sqrt(__builtin_fma(B, B, -(4 * A * C)))) / (2 * A);
+  return (-B + ds_sqrt_dev(__builtin_fma(B, B, -(4 * A * C)))) / (2 * A);
 }
 
 /* simulations.py:234-275 on a pre-gathered record {A, E1 = B - A, E2 = C - A}
