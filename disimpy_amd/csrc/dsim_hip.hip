@@ -1074,6 +1074,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       q.t_begin = ta, q.t_end = tb;
       q.tile_steps = tb - ta; /* gradient from global memory: one "tile" per launch */
       q.traj = g.traj;
+      q.rec_col = nullptr;
       q.tcur = nullptr, q.progress = nullptr, q.iter_budget = INT_MAX;
       q.m0 = 0, q.mc = 0, q.write_state = true;
       if (*g.ev_used + 2 > (int)g.ev->size()) {
@@ -1098,7 +1099,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
         const int mc = std::min(mb_phase, h->M - m0);
 #define DSIM_PHASE_LAUNCH_G(MBV)                                                                                                    \
   phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, v->stream>>>(g.traj, v->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, p.gdt, v->phase, \
-                                                                 h->phase_stride)
+                                                                 h->phase_stride, nullptr)
         switch (mb_phase) {
           case 4: DSIM_PHASE_LAUNCH_G(4); break;
           case 8: DSIM_PHASE_LAUNCH_G(8); break;
@@ -1366,7 +1367,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   }
   /* mesh: re-sort every `resort` steps (auto: the time a walker needs to diffuse ~half a subvoxel) */
   int resort = 0;
-  if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX && !h->recording) {
+  /* [r4] also while recording for the caller: the kernels then record through the slot -> walker map (rec_col) */
+  if (geom == GEOM_MESH && h->resort_steps >= 0 && h->n >= 4096 && h->n < (int64_t)INT32_MAX) {
     resort = h->resort_steps;
     if (resort == 0) {
       double hmin = 1e300;
@@ -1480,7 +1482,12 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     p.exc = h->exc;
     p.t_begin = ta;
     p.t_end = tb;
-    p.traj = record ? h->traj : nullptr;
+    /* a recording for the caller holds the whole range of the call, in walker order: launch [ta, tb) writes its part,
+     * every slot into the column of the walker it holds */
+    double *traj_launch = record ? h->traj + (h->recording ? (size_t)(ta - t_begin) * 3 * (size_t)h->n : 0) : nullptr;
+    const int32_t *rec_col = (h->recording && permuted) ? h->orig[h->orig_cur] : nullptr;
+    p.traj = traj_launch;
+    p.rec_col = rec_col;
     p.tcur = nullptr;
     p.iter_budget = INT_MAX;
     for (int pass = 0; pass < passes; pass++) {
@@ -1516,8 +1523,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       for (int m0 = walk_meas; m0 < h->M; m0 += mb_all) {
         const int mc = std::min(mb_all, h->M - m0);
 #define DSIM_PHASE_LAUNCH(MBV)                                                                                             \
-  phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(h->traj, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \
-                                                                 p.gdt, h->phase, h->phase_stride)
+  phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, h->stream>>>(traj_launch, h->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, \
+                                                                 p.gdt, h->phase, h->phase_stride, rec_col)
         switch (mb_all) {
           case 1: DSIM_PHASE_LAUNCH(1); break;
           case 2: DSIM_PHASE_LAUNCH(2); break;

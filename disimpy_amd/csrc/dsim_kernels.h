@@ -116,6 +116,9 @@ struct WalkParams {
   double eps, perm_prob;
   MeshDev mesh;
   double *traj; /* walk_kernel_coop4_traj: [t - t_begin][3][n], the positions after every time step of the launch */
+  /* recording for the caller (dsim_set_recording) while the walkers sit in sorted slots: slot i records into column
+   * rec_col[i] - its walker's index - so that the recording comes out in walker order; nullptr: column i */
+  const int32_t *rec_col;
   /* cooperative mesh kernel with per-walker clocks (dsim_hip.hip, run_own_clock): tcur[i] = the next time step of walker i
    * on entry and on exit; the launch ends when every wavefront has run iter_budget passes (walkers inside a step
    * finish it) or all its walkers have reached t_end.  nullptr: every walker runs [t_begin, t_end). */
@@ -546,6 +549,8 @@ DSD void walk_body(const WalkParams &p_arg) {
   double ph[MB];
 #pragma unroll
   for (int m = 0; m < MB; m++) ph[m] = 0;
+  int64_t rec_i = i;
+  if (TRAJ && live && p.rec_col != nullptr) rec_i = p.rec_col[i];
   if (live) {
     r.x = p.x_in[i];
     r.y = p.y_in[i];
@@ -616,7 +621,7 @@ DSD void walk_body(const WalkParams &p_arg) {
           r.y = __builtin_fma(step.y, sl, r.y);
           r.z = __builtin_fma(step.z, sl, r.z);
           if (TRAJ) {
-            double *q = p.traj + (int64_t)(t0 + k_lane - p.t_begin) * 3 * p.n + i;
+            double *q = p.traj + (int64_t)(t0 + k_lane - p.t_begin) * 3 * p.n + rec_i;
             q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
           }
           if (TRAJ) {
@@ -687,7 +692,7 @@ DSD void walk_body(const WalkParams &p_arg) {
           step_mesh<KA>(r, step, p.step_l, p_arg, xs, ys, zs, rng, exc);
         }
         if (TRAJ) {
-          double *q = p.traj + (int64_t)(t0 + k - p.t_begin) * 3 * p.n + i;
+          double *q = p.traj + (int64_t)(t0 + k - p.t_begin) * 3 * p.n + rec_i;
           q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
         }
         /* phases[m, i] += GAMMA*dt*(gx*x + gy*y + gz*z), e.g. simulations.py:692-701 */
@@ -770,10 +775,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 template <int MB>
 __global__ __launch_bounds__(256) void phase_from_traj_kernel(const double *traj, int64_t n, int steps, int tile_steps, const double *g4,
                                                               int M, int m0, int mc, int t_first, double gdt, double *phase,
-                                                              int64_t phase_stride) {
+                                                              int64_t phase_stride, const int32_t *rec_col) {
   extern __shared__ double gt[];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
+  const int64_t rec_i = live && rec_col != nullptr ? (int64_t)rec_col[i] : i; /* where slot i's walker was recorded (WalkParams::rec_col) */
   double ph[MB];
 #pragma unroll
   for (int m = 0; m < MB; m++) ph[m] = (live && m < mc) ? phase[(int64_t)(m0 + m) * phase_stride + i] : 0.0;
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(256) void phase_from_traj_kernel(const double *traj
     __syncthreads();
     if (live) {
       for (int k = 0; k < kt; k++) {
-        const double *q = traj + (int64_t)(t0 + k) * 3 * n + i;
+        const double *q = traj + (int64_t)(t0 + k) * 3 * n + rec_i;
         const double x = q[0], y = q[n], z = q[2 * n];
         const double *g = gt + k * (MB * 4);
 #pragma unroll

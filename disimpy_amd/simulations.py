@@ -318,7 +318,9 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             # the trajectories file needs the positions after every step: the device records them
             # and hands them over once per range of steps (<= 64 MB) instead of once per step
             sim.set_recording(True)
-            chunk = max(1, min(n_t, (1 << 30) // (24 * max(1, b - a))))  # <= 1 GB of recorded positions per range
+            # <= 8 GB of recorded positions per range (a mesh run re-sorts its walkers inside a range like any other mesh
+            # run - the device records through the slot -> walker map - so the ranges need not be short)
+            chunk = max(1, min(n_t, (1 << 33) // (24 * max(1, b - a))))
         elif quiet:
             chunk = n_t
         else:

@@ -28,7 +28,8 @@
  *     results); the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
  *     i.e. n_sv[0] + n_sv[1] + n_sv[2] below about 14 000;
  *   - spatial re-sorting of the walker slots (mesh substrates) needs 4096 <= n_walkers < 2^31
- *     per handle; outside that range the run proceeds unsorted (slower, same results);
+ *     per handle; outside that range the run proceeds unsorted (slower, same results); a recording run
+ *     (dsim_set_recording) is sorted like any other - the kernels record slot i into the column of its walker;
  *   - recording (dsim_set_recording): the range of one dsim_run_* call must fit 32 GB of
  *     positions (24 bytes per walker and step); M > 32 or mesh runs with M > 2 record
  *     internally and cut their launches to what the device can spare instead;

@@ -267,10 +267,14 @@ def test_recording_with_forced_measurements_per_pass(lib, oracle_exact, M, meas_
     npt.assert_array_equal(rec, traj)
 
 
-@pytest.mark.parametrize("kind", ["free", "sphere", "mesh"])
+@pytest.mark.parametrize("kind", ["free", "sphere", "mesh", "mesh re-sorted every 7 steps"])
 def test_recorded_trajectories_equal_the_oracles(lib, oracle_exact, kind):
     """dsim_set_recording / dsim_get_recorded against the ORACLE's per-step positions (want_traj:
-    what the reference writes to its trajectories file, simulations.py:1043-1048, :1211-1213)."""
+    what the reference writes to its trajectories file, simulations.py:1043-1048, :1211-1213).  A mesh run is re-sorted
+    in space while it records (round 4: slot i records into the column of its walker, several launches per call each
+    writing its part of the range): the recording still comes out in walker order."""
+    resort = 7 if "re-sorted" in kind else 0
+    kind = kind.split()[0]
     from disimpy_amd import substrates
 
     n, T, dt = 5000, 30, 5e-4
@@ -297,6 +301,8 @@ def test_recorded_trajectories_equal_the_oracles(lib, oracle_exact, kind):
         if kind == "mesh":
             sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
         sim.set_recording(True)
+        if resort:
+            sim.set_tuning(resort_steps=resort)
         rec = []
         for t0, t1 in ((0, 17), (17, T)):
             if kind == "free":
