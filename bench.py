@@ -23,7 +23,7 @@ cooperative mesh walk kernel): bound "hbm", `achieved` = ALGORITHMIC bytes per l
 80 + 16 M bytes per spin-step x the spin-steps of a launch) over the kernel's average launch duration,
 measured in THIS run with HIP events on the library's streams; `traffic` = the HBM bytes per launch from
 the PMC counters in profiles/kernel_counters.json.  The kernel keeps all walker state in registers, so
-HBM is not what bounds it (frac ~ 0.15): the bound that holds - vector-ALU issue - is reported next to it
+HBM is not what bounds it (frac ~ 0.18): the bound that holds - vector-ALU issue - is reported next to it
 in `roofline.valu` (VALU wave-instructions per wavefront-step from the rocprofv3 SQ_INSTS_VALU count of the
 same kernel, times the wavefront-steps per second of this run, over 1024 SIMDs x 2.4 GHz / 4 cycles), but
 only when the counters were collected from the library that is running (`counters_match_lib`: sha256 of
