@@ -514,20 +514,26 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     int n_items = 0;        /* items waiting in the queue (wave-uniform) */
     int n_surv = 0;         /* survivors waiting in the pool (wave-uniform) */
     bool drain_all = false; /* the next run does not fit behind the waiting items */
-    /* records of a run in two steps, so that the look-ups of a lane's two runs are in flight together: first the cell slot
-     * (one load: sv_base), then {first record, number of records} (two loads: cell_start) */
-    auto cell_of = [&](const uint2 &e) -> int {
-      if (e.x == 0xffffffffu) return -1;
-      STAT_LANE(5);
-      STAT_WAVE(5);
-      if (lk == 0) return (int)e.y;
-      const int base = ms.sv_base[e.y >> lcs];
-      return base >= 0 ? base + (int)(e.y & cmask) : -1;
-    };
-    auto records_of = [&](const uint2 &e, int cell) -> int2 {
-      if (cell < 0 || ABLATE(2)) return make_int2(0, 0);
-      const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
-      return make_int2((int)r0i, (int)(r1i - r0i));
+    /* records of a run: {first record, number of records} */
+    auto look_up = [&](const uint2 &e) -> int2 {
+      int first = 0, cnt = 0;
+      if (e.x != 0xffffffffu) {
+        STAT_LANE(5);
+        STAT_WAVE(5);
+        int cell = (int)e.y;
+        bool some = true;
+        if (lk > 0) {
+          const int base = ms.sv_base[e.y >> lcs];
+          some = base >= 0;
+          cell = base + (int)(e.y & cmask);
+        }
+        if (some && !ABLATE(2)) {
+          const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
+          first = (int)r0i;
+          cnt = (int)(r1i - r0i);
+        }
+      }
+      return make_int2(first, cnt);
     };
     /* the records of a run as items of four; the last one holds what is left (its count goes in after the loop: the loop
      * itself is one store and two additions per item - its trip count is the longest run of the 64) */
@@ -552,12 +558,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             eb = make_run(ms, o, q, (int)(m >> 6));
           }
         }
-        const int ca = cell_of(ea);
-        int cb = -1;
-        if (extras) cb = cell_of(eb);
-        const int2 ra = records_of(ea, ca);
+        const int2 ra = look_up(ea);
         int2 rb = make_int2(0, 0);
-        if (extras) rb = records_of(eb, cb);
+        if (extras) rb = look_up(eb);
         const int nba = (ra.y + 3) >> 2, nbb = (rb.y + 3) >> 2, nb = nba + nbb;
         if (nb > 0) {
           STAT_LANE(3);
