@@ -1260,20 +1260,27 @@ DSD int fill_count_reference_order(const FillParams &p, const V3 &pt, int llx, i
   return n_hits;
 }
 
-/* The triangles a +x ray from pt meets in the bucket of its (y, z) column (FillParams::mcol): the number of distinct
- * ones, FILL_MAX_HITS or more when the reference's give-up rule (simulations.py:478-479) has to decide */
-DSD int fill_count_bucket(const FillParams &p, const double *ys, const double *zs, const V3 &pt, int col, int lly, int llz, int llx, int ulx) {
+/* bucket of the point pt in its (y, z) column lly, llz (FillParams::mcol): {first entry, end} of ment, or {0, 0} when the
+ * column holds no triangle at all */
+DSD int2 fill_bucket(const FillParams &p, const double *ys, const double *zs, const V3 &pt, int lly, int llz) {
   const MeshDev &ms = p.mesh;
-  const V3 ray = {1.0, 0.0, 0.0};
-  const int2 mc = p.mcol[col];
+  const int2 mc = p.mcol[lly * ms.nz + llz];
+  if (mc.x < 0) return make_int2(0, 0);
   const int G = mc.y;
   int iy = (int)((pt.y - ys[lly]) * ((double)G * ms.inv_hy)), iz = (int)((pt.z - zs[llz]) * ((double)G * ms.inv_hz));
   iy = min(max(iy, 0), G - 1), iz = min(max(iz, 0), G - 1);
   const int b = mc.x + iy * G + iz;
+  return make_int2(p.mstart[b], p.mstart[b + 1]);
+}
+
+/* The triangles a +x ray from pt meets among the entries [begin, end) of its bucket: the number of distinct ones,
+ * FILL_MAX_HITS or more when the reference's give-up rule (simulations.py:478-479) has to decide */
+DSD int fill_count_bucket(const FillParams &p, const V3 &pt, int begin, int end, int llx, int ulx) {
+  const MeshDev &ms = p.mesh;
+  const V3 ray = {1.0, 0.0, 0.0};
   const float fy = (float)pt.y, fz = (float)pt.z;
-  const int end = p.mstart[b + 1];
   int n_hits = 0;
-  for (int i = p.mstart[b]; i < end; i++) {
+  for (int i = begin; i < end; i++) {
     const int2 en = p.ment[i];
     const int x = en.y >> 16, prev = (en.y & 0xffff) - 1;
     if (x < llx) break; /* descending x: the rest of the bucket lies behind the point */
@@ -1303,6 +1310,7 @@ struct FillQueue {
   double x[FILL_QUEUE_CAP], y[FILL_QUEUE_CAP], z[FILL_QUEUE_CAP];
   uint32_t key[FILL_QUEUE_CAP]; /* launch << 8 | thread inside the workgroup */
   int32_t llx[FILL_QUEUE_CAP], ulx[FILL_QUEUE_CAP], col[FILL_QUEUE_CAP]; /* col = lly << 16 | llz */
+  int32_t begin[FILL_QUEUE_CAP], end[FILL_QUEUE_CAP];                     /* the bucket's entries */
 };
 
 /* A BATCH of the reference's launches in one dispatch.  The reference launches _cuda_fill_mesh again and again - every
@@ -1315,7 +1323,7 @@ struct FillQueue {
  * Most candidates are decided at once - their (y, z) column of the index holds no triangle at all (the neuron fills
  * 0.025 % of its voxel) - while one in a few has a bucket of triangles to walk, a loop of dependent look-ups whose
  * length differs from lane to lane.  Left in place that loop runs on nearly every launch for the few lanes that need
- * it; here those candidates are QUEUED per wavefront (point, key, x range, column: 40 bytes in LDS, slots from a
+ * it; here those candidates are QUEUED per wavefront (point, key, x range, column, bucket: 48 bytes in LDS, slots from a
  * ballot) and walked 64 at a time, whoever drew them.  An accepted candidate is parked in the workgroup's staging rows
  * with its (launch, thread) key; fill_scan_kernel and fill_place_kernel then put the batch in (launch, thread) order -
  * the order the reference's appends produce.  Candidates, counts and order are the reference's bit for bit
@@ -1356,7 +1364,7 @@ __global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p_arg)
       const V3 pt = {Q.x[q], Q.y[q], Q.z[q]};
       const FillParams &p = fresh_fill(p_arg);
       const int lly = Q.col[q] >> 16, llz = Q.col[q] & 0xffff, llx = Q.llx[q], ulx = Q.ulx[q];
-      int n_hits = fill_count_bucket(p, ys, zs, pt, lly * p.mesh.nz + llz, lly, llz, llx, ulx);
+      int n_hits = fill_count_bucket(p, pt, Q.begin[q], Q.end[q], llx, ulx);
       if (n_hits >= FILL_MAX_HITS) n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, lly + 1, llz, llz + 1);
       const bool inside = (n_hits & 1) == 1;
       if (n_hits >= 0 && (p.intra ? inside : !inside)) park(pt, Q.key[q]);
@@ -1369,6 +1377,7 @@ __global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p_arg)
     bool need = false, accept = false;
     V3 pt = {0, 0, 0};
     int llx = 0, ulx = 0, col = 0;
+    int2 bucket = make_int2(0, 0);
     if (live) {
       pt.x = rng_uniform_f64(rng) * p.voxel[0];
       pt.y = rng_uniform_f64(rng) * p.voxel[1];
@@ -1385,7 +1394,13 @@ __global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p_arg)
       int n_hits = 0;
       if (uly - lly == 1 && ulz - llz == 1) {
         col = (lly << 16) | llz; /* n_sv <= 4096 per axis */
-        need = p.mcol[lly * ms.nz + llz].x >= 0; /* the column holds triangles: its bucket is walked with the next full trip */
+        /* the point's bucket of its column holds triangles: it is walked with the next full trip (an empty bucket - four
+         * in five of a column that a dendrite crosses - decides the candidate here and now: no triangle, outside) */
+        bucket = fill_bucket(p, ys, zs, pt, lly, llz);
+        need = bucket.y > bucket.x;
+#ifdef DSIM_FILL_ABLATE /* development build: DSIM_FILL_ABLATE=1 no bucket is walked (timing of the draws and look-ups alone), 2: nothing but the draws */
+        if (DSIM_FILL_ABLATE >= 1) need = false;
+#endif
       } else if (uly > lly && ulz > llz) {
         n_hits = fill_count_reference_order(p, pt, llx, ulx, lly, uly, llz, ulz); /* cannot happen (see above); the reference's loop decides */
       }
@@ -1399,6 +1414,7 @@ __global__ __launch_bounds__(256) void fill_batch_kernel(const FillParams p_arg)
         Q.x[q] = pt.x, Q.y[q] = pt.y, Q.z[q] = pt.z;
         Q.key[q] = ((uint32_t)l << 8) | threadIdx.x;
         Q.llx[q] = llx, Q.ulx[q] = ulx, Q.col[q] = col;
+        Q.begin[q] = bucket.x, Q.end[q] = bucket.y;
       }
       n_q += (int)__popcll(m);
       wave_sync();
