@@ -700,6 +700,56 @@ void dso_u_div3(double *v, double length) { ds_div3(&v[0], &v[1], &v[2], length)
 double dso_u_cos(double x) { return DSO_COS(x); }
 size_t dso_sizeof_geom(void) { return sizeof(dso_geom); }
 
+/* EXHAUSTIVE pins of the two table functions of the random step (tests/test_dsim_math.py), over every float32 with bit
+ * pattern in [bits_lo, bits_hi) - a float32 uniform is one of the 4.4e8 floats of [2^-53, 1] (numba/cuda/random.py:199-221:
+ * u1 feeds the log, 2 pi u2 the cosine).  The yardstick is the x87 long double function (64-bit significand) rounded once.
+ *   dso_u_logf_sweep: how many inputs give something else than RN_float32(logl(x)); the first such input in *first_bad
+ *   dso_u_cos_sweep:  max |cos(6.283185307179586 * u) - cosl(same argument)| over the range, and the largest such error
+ *                     in units of the result's ulp where |cos| >= 1/2 */
+int64_t dso_u_logf_sweep(uint32_t bits_lo, uint32_t bits_hi, uint32_t *first_bad) {
+  int64_t bad = 0;
+  uint32_t first = 0xffffffffu;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(min : first)
+  for (int64_t b = (int64_t)bits_lo; b < (int64_t)bits_hi; b++) {
+    union {
+      uint32_t u;
+      float f;
+    } in;
+    in.u = (uint32_t)b;
+    const float got = DSO_LOGF(in.f), want = (float)logl((long double)in.f);
+    if (!(got == want)) {
+      bad++;
+      if ((uint32_t)b < first) first = (uint32_t)b;
+    }
+  }
+  if (first_bad) *first_bad = first;
+  return bad;
+}
+
+void dso_u_cos_sweep(uint32_t bits_lo, uint32_t bits_hi, double *max_abs_err, double *max_ulp_err_big) {
+  double ea = 0, eu = 0;
+#pragma omp parallel for schedule(static) reduction(max : ea) reduction(max : eu)
+  for (int64_t b = (int64_t)bits_lo; b < (int64_t)bits_hi; b++) {
+    union {
+      uint32_t u;
+      float f;
+    } in;
+    in.u = (uint32_t)b;
+    const double x = 6.283185307179586 * (double)in.f;
+    const double got = DSO_COS(x);
+    const long double want = cosl((long double)x);
+    const double err = (double)fabsl((long double)got - want);
+    if (err > ea) ea = err;
+    if (fabsl(want) >= 0.5L) {
+      const double w = (double)want;
+      const double ulp = nextafter(fabs(w), INFINITY) - fabs(w);
+      if (err / ulp > eu) eu = err / ulp;
+    }
+  }
+  *max_abs_err = ea;
+  *max_ulp_err_big = eu;
+}
+
 /* The mesh kernel's reflect loop (simulations.py:924-997) on caller-supplied rays - the CPU twin of dsu_mesh_pass()
  * in disimpy_amd/csrc/dsim_unit.hip, for the adversarial traversal tests (rays through shared edges and vertices,
  * rays in subvoxel boundary planes, hits at d == step_l, far periodic images).  Walker i starts at r0[i] with

@@ -106,6 +106,10 @@ class Oracle:
         lib.dso_u_logf.restype = C.c_float
         lib.dso_u_cos.argtypes = [C.c_double]
         lib.dso_u_cos.restype = C.c_double
+        lib.dso_u_logf_sweep.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.dso_u_logf_sweep.restype = C.c_int64
+        lib.dso_u_cos_sweep.argtypes = [C.c_uint32, C.c_uint32, _f64p, _f64p]
+        lib.dso_u_cos_sweep.restype = None
         lib.dso_u_mesh_pass.argtypes = [C.POINTER(Geom), C.c_int64, C.c_int64, _f64p, _f64p, _f64p, C.c_void_p,
                                         C.POINTER(C.c_int32)]
         lib.dso_u_mesh_pass.restype = None

@@ -59,3 +59,33 @@ def test_div3_equals_ieee_division(oracle_exact):
         lib.dso_u_div3(g.ctypes.data_as(C.POINTER(C.c_double)), bad)
         with np.errstate(all="ignore"):
             np.testing.assert_array_equal(g, np.array([1.0, 0.0, -2.0]) / bad)
+
+
+def _f32_bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def test_logf_is_correctly_rounded_on_every_possible_uniform(oracle_exact):
+    """EXHAUSTIVE: a float32 uniform of the random step (numba/cuda/random.py:199-221 - the 53-bit fraction rounded to
+    float32) is 0 or one of the 444 596 225 floats of [2^-53, 1]; on every one of them ds_logf returns the correctly rounded
+    logarithm (the x87 long double logl rounded once to float32).  The bit-identity tests compare the kernels with an
+    oracle that shares dsim_math.h - this test is what says the shared function is the right one."""
+    import ctypes as C
+
+    first_bad = C.c_uint32(0)
+    lo, hi = _f32_bits(2.0**-53), _f32_bits(1.0) + 1
+    assert hi - lo == 444596225
+    bad = oracle_exact.lib.dso_u_logf_sweep(lo, hi, C.byref(first_bad))
+    assert bad == 0, "first wrong input: bits %#x" % first_bad.value
+
+
+def test_cos_error_on_every_possible_uniform(oracle_exact):
+    """EXHAUSTIVE: cos(6.283185307179586 * u2) for every float32 u2 of [2^-53, 1]: within 1.2e-16 of the long double
+    cosine everywhere, within 1.01 ulp of it where |cos| >= 1/2 (measured: 1.116e-16 and 1.0054 ulp)."""
+    import ctypes as C
+
+    a, b = np.zeros(1), np.zeros(1)
+    p = C.POINTER(C.c_double)
+    oracle_exact.lib.dso_u_cos_sweep(_f32_bits(2.0**-53), _f32_bits(1.0) + 1, a.ctypes.data_as(p), b.ctypes.data_as(p))
+    assert 0 < a[0] < 1.2e-16
+    assert b[0] < 1.01

@@ -37,6 +37,10 @@ run_one() {
       for cfg in "10000000 4" "10000000 8" "10000000 32" "5000000 1" "2500000 1" "1250000 1" "1250000 32"; do set -- $cfg
         timeout -k 5 400 python bench.py --workload c5b --walkers $1 --measurements $2 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5b walkers $1 M=$2: value %.4g walk-kernel %.4g' % (d['value'], d['walk_kernel_spin_steps_per_s']))"
       done > $O/rates_by_size_and_measurements.txt 2>&1
+      # the two headline lines once more, now that profiles/kernel_counters.json belongs to this build
+      timeout -k 10 700 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
+      timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command_line.json 2> $O/bench_driver_command.err
+      python tools/dev/fillcheck.py 30000 > $O/fill_neuron_30000_points_vs_oracle.txt 2>&1
       cat $O/rates_by_size_and_measurements.txt; tail -25 $O/pmc_c5b.txt ;;
   esac
 }
