@@ -2126,8 +2126,8 @@ static int fill_open_impl(dsim_fill *fs, int64_t thread_begin, int intra, uint64
       ent_yz.push_back(make_float4(0, 0, 0, 0));
     }
     /* the bucketed copy (FillParams::mcol): G x G buckets over the cross-section of every non-empty column,
-     * entries in descending x; a triangle goes into every bucket its float32 extent (already rounded outward)
-     * reaches, widened by 1e-6 bucket widths against the rounding of the kernel's own bucket arithmetic */
+     * entries in descending x; a triangle goes into the buckets its (y, z) PROJECTION reaches, among those of its float32
+     * extent (rounded outward), every bucket widened by 1e-6 widths against the kernel's own bucket arithmetic */
     std::vector<int2> mcol((size_t)ny * nz, make_int2(-1, 0)), ment;
     std::vector<int32_t> mstart;
     std::vector<float4> ment_yz;
