@@ -984,6 +984,25 @@ struct WalkGroup {
   bool permuted = false, inflight = false;
 };
 
+/* Dynamic LDS the phase kernel asks for WITHOUT using it: with none, its workgroups (112 VGPRs, no LDS of their own) slip
+ * into every CU next to the other walker group's walk workgroups and stream the recorded positions - 17 GB per launch of
+ * 5e6 walkers - through the L2s the traversal's index lives in; the walk kernel slows by more than the overlap is worth
+ * (C5b, 1e7 walkers, M = 32: 1.025e10 against 1.04e10 for the round-3 kernel, which never found a slot and ran in the gap
+ * between two walk kernels).  Asking for a little more LDS than a CU has left beside a full set of walk workgroups lets a
+ * phase workgroup in only where a walk workgroup has retired - one per CU while the walk kernel runs, several once it
+ * drains: 1.08e10, and 9.35e9 against 8.83e9 at 1.25e6 walkers (profiles/history/r04_ab_m32_phase_kernel_dpp.txt: 0 / 20 /
+ * 28 / 32 / 40 / 48 / 64 KB asked for give 1.025-1.037 / 1.025 / 1.077 / 1.081 / 1.065 / 1.001 / 1.05e10).
+ * walk_lds: dynamic LDS of one walk workgroup.  DSIM_PHASE_LDS (bytes) overrides it in tuning runs. */
+static size_t phase_lds_reserve(size_t walk_lds) {
+  if (const char *e = getenv("DSIM_PHASE_LDS")) return (size_t)atol(e);
+  const size_t cu = 160 * 1024, granule = 1280;
+  const size_t per_wg = std::max<size_t>((walk_lds + granule - 1) / granule * granule, granule);
+  const size_t max_wg = std::min<size_t>(4, cu / per_wg); /* 4 waves per SIMD: at most four workgroups of 256 */
+  if (max_wg == 0) return 0;
+  const size_t left = cu - max_wg * per_wg;
+  return std::min<size_t>(std::min<size_t>(left + 8 * 1024, cu - (max_wg - 1) * per_wg), 64 * 1024);
+}
+
 static int walker_groups(const dsim_sim *h) {
   int want = 0; /* development override: DSIM_GROUPS=1..4 (see include/dsim.h, environment) */
   if (const char *e = getenv("DSIM_GROUPS")) want = atoi(e);
@@ -1093,7 +1112,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       *g.ev_used += 2;
       h->last_launches++;
       const int tile_p = std::max(1, 16384 / (mb_phase * 32));
-      const size_t lds_p = (size_t)tile_p * mb_phase * 4 * sizeof(double);
+      const size_t lds_p = n_groups > 1 ? phase_lds_reserve(lds) : 0; /* asked for, not used: see phase_lds_reserve */
       const int grid_p = grid_for(v->n, 256);
       for (int m0 = 0; m0 < h->M; m0 += mb_phase) {
         const int mc = std::min(mb_phase, h->M - m0);
@@ -1518,7 +1537,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
     h->cur = dst;
     if (record) {
       const int tile_p = std::max(1, 16384 / (mb_all * 32));
-      const size_t lds_p = (size_t)tile_p * mb_all * 4 * sizeof(double);
+      const size_t lds_p = 0; /* one stream: nothing to keep out of the way of (the samples come through L1 and DPP row broadcasts) */
       const int grid_p = grid_for(h->n, 256);
       for (int m0 = walk_meas; m0 < h->M; m0 += mb_all) {
         const int mc = std::min(mb_all, h->M - m0);

@@ -508,11 +508,43 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p_arg, con
 
 #include "dsim_mesh_coop.h"
 
+/* lane J of every row of 16 lanes, broadcast to its row - as an operand modifier of the two fp64 VALU operations
+ * that accept one on gfx90a and later (DPP row_newbcast on v_mov_b64 and v_fmac_f64).  Every lane of the wavefront has to be
+ * active, and the broadcast register must not have been written by a VALU instruction two issue slots earlier (the
+ * callers load it from memory and fence with dpp_fence). */
+template <int J>
+DSD double row_bcast(double v) {
+  double r;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+  return r;
+}
+/* acc = fma(lane J of g in this row, v, acc) */
+template <int J>
+DSD void row_fmac(double &acc, double g, double v) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(v), "n"(J));
+}
+DSD void dpp_fence(double &a, double &b, double &c) { asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c)); }
+
+/* measurements M0 .. M0 + 15 of one time step: gx, gy, gz hold, in lane j of every row, the gradient sample of
+ * measurement M0 + j; the same operations in the same order as the fused kernels (walk_body):
+ * inner = fma(gz, z, fma(gx, x, gy * y)), phase = fma(gdt, inner, phase) */
+template <int M0, int J, int MB>
+DSD void phase_step16(double (&ph)[MB], double gx, double gy, double gz, double x, double y, double z, double gdt) {
+  if constexpr (J < 16 && M0 + J < MB) {
+    double inner = row_bcast<J>(gy) * y;
+    row_fmac<J>(inner, gx, x);
+    row_fmac<J>(inner, gz, z);
+    ph[M0 + J] = __builtin_fma(gdt, inner, ph[M0 + J]);
+    phase_step16<M0, J + 1, MB>(ph, gx, gy, gz, x, y, z, gdt);
+  }
+}
+
 /* ---- the fused kernel --------------------------------------------------------- */
 
 template <int GEOM, int MB, int GSRC, int COOP, int TRAJ = 0, int KA = 0>
 DSD void walk_body(const WalkParams &p_arg) {
   const WalkParams &p = fresh_params<KA>(p_arg);
+  constexpr bool ROWG = GSRC == 0 && MB >= 16 && GEOM != GEOM_MESH; /* gradient samples through DPP row broadcasts (analytic substrates) */
   extern __shared__ double lds[];
   double *log_tab = lds;                           /* 128 doubles                     */
   double *cos_tab = lds + DS_LOG_TABLE_DOUBLES;    /* 514 doubles                     */
@@ -551,16 +583,17 @@ DSD void walk_body(const WalkParams &p_arg) {
   for (int m = 0; m < MB; m++) ph[m] = 0;
   int64_t rec_i = i;
   if (TRAJ && live && p.rec_col != nullptr) rec_i = p.rec_col[i];
-  if (live) {
-    r.x = p.x_in[i];
-    r.y = p.y_in[i];
-    r.z = p.z_in[i];
-    rng.s0 = p.s0_in[i];
-    rng.s1 = p.s1_in[i];
-    exc = p.exc[i] != 0;
+  if (live || ROWG) {
+    const int64_t ii = live ? i : p.n - 1; /* ROWG: a surplus lane walks a copy of the last walker and stores nothing */
+    r.x = p.x_in[ii];
+    r.y = p.y_in[ii];
+    r.z = p.z_in[ii];
+    rng.s0 = p.s0_in[ii];
+    rng.s1 = p.s1_in[ii];
+    exc = p.exc[ii] != 0;
 #pragma unroll
     for (int m = 0; m < MB; m++)
-      if (m < p.mc) ph[m] = p.phase[(int64_t)(p.m0 + m) * p.phase_stride + i];
+      if (m < p.mc) ph[m] = p.phase[(int64_t)(p.m0 + m) * p.phase_stride + ii];
   }
 
   for (int t0 = p.t_begin; t0 < p.t_end; t0 += p.tile_steps) {
@@ -673,7 +706,7 @@ DSD void walk_body(const WalkParams &p_arg) {
       if (lane == 0)
         for (int q = 0; q < 16; q++) atomicAdd(&dsim_timers[q], coop->tacc[q]);
 #endif
-    } else if (live) {
+    } else if (live || ROWG) { /* ROWG: the row broadcasts want every lane active */
       for (int k = 0; k < kt; k++) {
         const WalkParams &p = fresh_params<KA>(p_arg); /* mesh (KA = 1): no launch parameter stays in SGPRs across time steps */
         V3 step = random_step(rng, log_tab, cos_tab);
@@ -691,12 +724,28 @@ DSD void walk_body(const WalkParams &p_arg) {
         } else {
           step_mesh<KA>(r, step, p.step_l, p_arg, xs, ys, zs, rng, exc);
         }
-        if (TRAJ) {
+        if (TRAJ && live) {
           double *q = p.traj + (int64_t)(t0 + k - p.t_begin) * 3 * p.n + rec_i;
           q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
         }
         /* phases[m, i] += GAMMA*dt*(gx*x + gy*y + gz*z), e.g. simulations.py:692-701 */
-        if (GSRC == 0) {
+        if (ROWG) {
+          /* 16 or more accumulators: read at a wave-uniform address, the samples of a step cost 2 LDS reads per
+           * measurement - 12 cycles of the CU's one LDS pipe for every 4 fp64 operations of one of its four SIMDs.
+           * Lane j of every row of 16 reads the sample of measurement j instead and the FMAs take it from there with
+           * a DPP row broadcast (phase_step16): 2 reads per 16 measurements, one more VALU operation per measurement */
+          const double *g = gt + k * (MB * 4) + (int)(threadIdx.x & 15u) * 4;
+          double2 axy = *reinterpret_cast<const double2 *>(g);
+          double az = g[2];
+          dpp_fence(axy.x, axy.y, az);
+          phase_step16<0, 0, MB>(ph, axy.x, axy.y, az, r.x, r.y, r.z, p.gdt);
+          if (MB > 16) {
+            double2 bxy = *reinterpret_cast<const double2 *>(g + 64);
+            double bz = g[66];
+            dpp_fence(bxy.x, bxy.y, bz);
+            phase_step16<16, 0, MB>(ph, bxy.x, bxy.y, bz, r.x, r.y, r.z, p.gdt);
+          }
+        } else if (GSRC == 0) {
           /* every lane reads the same LDS address: broadcast */
           const double *g = gt + k * (MB * 4);
 #pragma unroll
@@ -770,44 +819,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
  * time steps of one launch, in the same order and with the same roundings as the fused kernels.
  * Used for mesh substrates with more than two measurements: the cooperative walk kernel then
  * carries no phase accumulators at all (128 VGPRs, 4 waves/SIMD whatever M is), writes 24 bytes
- * per walker and step, and this kernel - pure streaming + FMAs, a few per cent of the walk's
- * time - does the rest.  traj = [step][3][n]; the gradient tile lives in LDS as in walk_body. */
+ * per walker and step, and this kernel - streaming + FMAs - does the rest.  traj = [step][3][n].
+ * [r4] The gradient samples of a step are the same for every walker.  Read from an LDS tile at a wave-uniform address
+ * (rounds 1-3: 2 LDS reads per measurement and step, 12 LDS cycles for 4 fp64 operations) the LDS pipe of the CU, not
+ * its four SIMDs, set the pace: 19 ms per launch of 5e6 walkers x 143 steps x 32 measurements, a fifth of the HBM rate.
+ * Now lane j of every row of 16 loads the sample of measurement j (three loads per 16 measurements and step, out of
+ * L1) and the FMAs take it from there with a DPP row broadcast - no LDS, no barrier, 5 VALU operations per measurement
+ * and step.  tile_steps is not used any more. */
 template <int MB>
-__global__ __launch_bounds__(256) void phase_from_traj_kernel(const double *traj, int64_t n, int steps, int tile_steps, const double *g4,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void phase_from_traj_kernel(const double *traj, int64_t n, int steps, int tile_steps, const double *g4,
                                                               int M, int m0, int mc, int t_first, double gdt, double *phase,
                                                               int64_t phase_stride, const int32_t *rec_col) {
-  extern __shared__ double gt[];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  const int64_t rec_i = live && rec_col != nullptr ? (int64_t)rec_col[i] : i; /* where slot i's walker was recorded (WalkParams::rec_col) */
+  (void)tile_steps;
+  const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < n;
+  const int64_t i = live ? i_raw : n - 1; /* every lane stays active (row broadcasts); the surplus lanes redo the last walker and store nothing */
+  const int64_t rec_i = rec_col != nullptr ? (int64_t)rec_col[i] : i; /* where slot i's walker was recorded (WalkParams::rec_col) */
+  const int j = (int)(threadIdx.x & 15u);
   double ph[MB];
 #pragma unroll
-  for (int m = 0; m < MB; m++) ph[m] = (live && m < mc) ? phase[(int64_t)(m0 + m) * phase_stride + i] : 0.0;
-  for (int t0 = 0; t0 < steps; t0 += tile_steps) {
-    const int kt = min(tile_steps, steps - t0);
-    __syncthreads();
-    const int row = mc * 2;
-    const double2 *src = reinterpret_cast<const double2 *>(g4);
-    double2 *dst = reinterpret_cast<double2 *>(gt);
-    for (int e = threadIdx.x; e < kt * (MB * 2); e += blockDim.x) {
-      int k = e / (MB * 2), c = e - k * (MB * 2);
-      dst[e] = c < row ? src[((int64_t)(t_first + t0 + k) * M + m0) * 2 + c] : make_double2(0.0, 0.0);
+  for (int m = 0; m < MB; m++) ph[m] = m < mc ? phase[(int64_t)(m0 + m) * phase_stride + i] : 0.0;
+  /* lane j reads the samples of measurements m0 + j and m0 + 16 + j; beyond mc they are somebody else's samples or the
+   * padding behind the table (g4 is padded by 32 samples) and feed accumulators that are never stored */
+  const double *gp = g4 + ((int64_t)t_first * M + m0 + j) * 4;
+  const double *q = traj + rec_i;
+  double x = q[0], y = q[n], z = q[2 * n];
+  double2 axy = *reinterpret_cast<const double2 *>(gp), bxy = make_double2(0.0, 0.0);
+  double az = gp[2], bz = 0.0;
+  if (MB > 16) bxy = *reinterpret_cast<const double2 *>(gp + 64), bz = gp[66];
+  for (int k = 0; k < steps; k++) {
+    /* the next step's operands are on their way while this one's are used (the last step reads its own again) */
+    const int kn = min(k + 1, steps - 1);
+    const double *qn = traj + (int64_t)kn * 3 * n + rec_i;
+    const double *gn = gp + (int64_t)kn * M * 4; /* never beyond the last step: m0 + 31 <= M + 30 stays inside the padding */
+    const double xn = qn[0], yn = qn[n], zn = qn[2 * n];
+    const double2 axy_n = *reinterpret_cast<const double2 *>(gn);
+    const double az_n = gn[2];
+    double2 bxy_n = make_double2(0.0, 0.0);
+    double bz_n = 0.0;
+    if (MB > 16) bxy_n = *reinterpret_cast<const double2 *>(gn + 64), bz_n = gn[66];
+    dpp_fence(axy.x, axy.y, az);
+    phase_step16<0, 0, MB>(ph, axy.x, axy.y, az, x, y, z, gdt);
+    if (MB > 16) {
+      dpp_fence(bxy.x, bxy.y, bz);
+      phase_step16<16, 0, MB>(ph, bxy.x, bxy.y, bz, x, y, z, gdt);
     }
-    __syncthreads();
-    if (live) {
-      for (int k = 0; k < kt; k++) {
-        const double *q = traj + (int64_t)(t0 + k) * 3 * n + rec_i;
-        const double x = q[0], y = q[n], z = q[2 * n];
-        const double *g = gt + k * (MB * 4);
-#pragma unroll
-        for (int m = 0; m < MB; m++) {
-          double2 gxy = *reinterpret_cast<const double2 *>(g + m * 4);
-          double gz = g[m * 4 + 2];
-          double inner = __builtin_fma(gz, z, __builtin_fma(gxy.x, x, gxy.y * y));
-          ph[m] = __builtin_fma(gdt, inner, ph[m]);
-        }
-      }
-    }
+    x = xn, y = yn, z = zn;
+    axy = axy_n, az = az_n, bxy = bxy_n, bz = bz_n;
   }
   if (live) {
 #pragma unroll
