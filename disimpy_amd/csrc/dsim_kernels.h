@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void walk_kernel(const WalkParams p) {
   /* the mesh kernels (per-lane traversal, and the cooperative one with more than four accumulators) re-read their launch
    * parameters where they use them (fresh_params): read once, MeshDev alone is ~40 SGPRs that the traversal's loops
    * then spill through VGPR lanes */
-  walk_body<GEOM, MB, GSRC, COOP, 0, GEOM == GEOM_MESH ? 1 : 0>(p);
+  walk_body<GEOM, MB, GSRC, COOP, 0, (GEOM == GEOM_MESH || MB >= 16) ? 1 : 0>(p);
 }
 
 /* Cooperative mesh traversal with few phase accumulators: capped at 128 VGPRs (a handful of
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
  * of replaying the walk */
 template <int GEOM>
 __global__ __launch_bounds__(256) void walk_kernel_traj32(const WalkParams p) {
-  walk_body<GEOM, 32, 0, 0, 1, GEOM == GEOM_MESH ? 1 : 0>(p);
+  walk_body<GEOM, 32, 0, 0, 1, 1>(p);
 }
 
 /* the same, recording the position after every step in p.traj (phases are then accumulated by
