@@ -228,6 +228,7 @@ struct dsim_sim {
   double *phase_alt = nullptr;
   double *traj = nullptr; /* [steps][3][n] positions of the last launch (mesh with M > 2: phases from positions) */
   int traj_steps = 0;
+  size_t traj_doubles = 0; /* capacity of traj */
   /* hand-over of recorded positions: a copy stream of its own and two pinned staging buffers, so that the
    * D2H transfer of one block of steps overlaps the host's work (copy-out / text formatting) on the previous one */
   hipStream_t copy_stream = nullptr;
@@ -1051,7 +1052,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       g.v.phase += g.off, g.v.phase_alt += g.off, g.v.exc += g.off, g.v.exc_alt += g.off, g.v.bin_of += g.off;
     }
     g.permuted = presorted; /* orig[] already holds the walkers' original indices */
-    g.traj = recorded ? h->traj + (size_t)h->traj_steps * 3 * g.off : nullptr;
+    g.traj = recorded ? h->traj + (size_t)h->traj_steps * 4 * g.off : nullptr; /* walker-major rows of 32 bytes per step */
     g.t_pos = g.t_sorted = t_begin;
     g.unfinished = g.v.n;
     g.steps_left = (long long)g.v.n * (t_end - t_begin);
@@ -1093,6 +1094,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       q.t_begin = ta, q.t_end = tb;
       q.tile_steps = tb - ta; /* gradient from global memory: one "tile" per launch */
       q.traj = g.traj;
+      q.traj_row_steps = h->traj_steps; /* walker-major: one 32-byte store per walker and step */
       q.rec_col = nullptr;
       q.tcur = nullptr, q.progress = nullptr, q.iter_budget = INT_MAX;
       q.m0 = 0, q.mc = 0, q.write_state = true;
@@ -1111,14 +1113,13 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used + 1], v->stream));
       *g.ev_used += 2;
       h->last_launches++;
-      const int tile_p = std::max(1, 16384 / (mb_phase * 32));
-      const size_t lds_p = n_groups > 1 ? phase_lds_reserve(lds) : 0; /* asked for, not used: see phase_lds_reserve */
+      const size_t lds_p = std::max<size_t>(4 * PHASE_ROWS_LDS_PER_WAVE, n_groups > 1 ? phase_lds_reserve(lds) : 0); /* 32 KB of staging; see phase_lds_reserve */
       const int grid_p = grid_for(v->n, 256);
       for (int m0 = 0; m0 < h->M; m0 += mb_phase) {
         const int mc = std::min(mb_phase, h->M - m0);
 #define DSIM_PHASE_LAUNCH_G(MBV)                                                                                                    \
-  phase_from_traj_kernel<MBV><<<grid_p, 256, lds_p, v->stream>>>(g.traj, v->n, tb - ta, tile_p, h->g4, h->M, m0, mc, ta, p.gdt, v->phase, \
-                                                                 h->phase_stride, nullptr)
+  phase_from_rows_kernel<MBV><<<grid_p, 256, lds_p, v->stream>>>(g.traj, v->n, tb - ta, h->traj_steps, h->g4, h->M, m0, mc, ta, p.gdt, \
+                                                                 v->phase, h->phase_stride)
         switch (mb_phase) {
           case 4: DSIM_PHASE_LAUNCH_G(4); break;
           case 8: DSIM_PHASE_LAUNCH_G(8); break;
@@ -1419,24 +1420,29 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       HIP_TRY(hipMemsetAsync(h->sort_hist[g], 0, (((size_t)1 << h->sort_bits) + 1) * sizeof(uint32_t), h->stream));
   }
   h->rec_t0 = h->rec_t1 = 0;
+  /* the branch further down that lets the walker groups record per range of steps and adds the phases up from that */
+  const bool own_clock_recorded = coop4 && split_phase && !h->recording && resort > 0 && h->mesh_traversal != 5;
   if (record) {
     /* up to 32 GB of recorded positions (24 bytes per walker and step; MI355X: 288 GB), at most 1024 steps
-     * per launch; a recording run must hold its whole range */
-    const int64_t fit = (int64_t)(32ull << 30) / (h->n * 24);
+     * per launch; a recording run must hold its whole range.  The walker groups' own recording is walker-major with
+     * 32 bytes per walker and step (WalkParams::traj_row_steps): 43 GB, the same 143 steps at 1e7 walkers */
+    const int width = own_clock_recorded ? 4 : 3;
+    const int64_t fit = own_clock_recorded ? (int64_t)(43ull << 30) / (h->n * 32) : (int64_t)(32ull << 30) / (h->n * 24);
     int steps = (int)std::min<int64_t>(1024, std::max<int64_t>(16, fit));
     steps = std::min(steps, std::max(16, t_end - t_begin)); /* no more than this run needs */
     if (h->recording) {
       if (t_end - t_begin > fit) return fail(DSIM_ERR_INVALID, "recording: %d steps of %lld walkers do not fit 32 GB", t_end - t_begin, (long long)h->n);
       steps = std::max(steps, t_end - t_begin);
     }
-    if (h->traj && h->traj_steps < steps) {
+    if (h->traj && h->traj_doubles < (size_t)steps * width * h->n) {
       HIP_TRY(hipFree(h->traj));
       h->traj = nullptr;
+      h->traj_doubles = 0;
     }
     while (!h->traj) {
       /* not a recording run: shorter launches if the device cannot spare that much memory */
-      if (hipMalloc(&h->traj, (size_t)steps * 3 * h->n * sizeof(double)) == hipSuccess) {
-        h->traj_steps = steps;
+      if (hipMalloc(&h->traj, (size_t)steps * width * h->n * sizeof(double)) == hipSuccess) {
+        h->traj_doubles = (size_t)steps * width * h->n;
         break;
       }
       h->traj = nullptr;
@@ -1444,6 +1450,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
       if (h->recording || steps <= 16) return fail(DSIM_ERR_HIP, "no device memory for %d steps of recorded positions", steps);
       steps = std::max(16, steps / 2);
     }
+    h->traj_steps = (int)std::min<int64_t>(1 << 20, (int64_t)(h->traj_doubles / ((size_t)width * h->n))); /* steps the buffer holds in this layout */
+    if (own_clock_recorded) h->traj_steps &= ~1; /* rows of an even number of steps: phase_from_rows_kernel reads two at a time */
   }
   /* clearance map: mesh_traversal 2 = decide per launch, 4 = always, 3 (and the per-lane traversal) = never */
   const MeshDev clear_map = p.mesh;
@@ -1453,7 +1461,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   if (coop4 && resort > 0 && !record && passes == 1 && h->mesh_traversal != 5)
     return run_own_clock(h, p, clear_map, clear_auto, mb, block, lds, resort, t_begin, t_end);
   /* the same with more than two measurements: positions recorded per range of steps, phases added up from them */
-  if (coop4 && split_phase && !h->recording && resort > 0 && h->mesh_traversal != 5) {
+  if (own_clock_recorded) {
     if (clear_auto) p.mesh.clear_idx = nullptr;
     return run_own_clock(h, p, clear_map, false, mb, block, lds, resort, t_begin, t_end, mb_all);
   }
@@ -1630,6 +1638,7 @@ extern "C" int dsim_set_recording(dsim_handle h, int32_t enable) {
     HIP_TRY(hipFree(h->traj));
     h->traj = nullptr;
     h->traj_steps = 0;
+    h->traj_doubles = 0;
   }
   return DSIM_OK;
 }

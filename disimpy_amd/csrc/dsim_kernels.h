@@ -116,6 +116,12 @@ struct WalkParams {
   double eps, perm_prob;
   MeshDev mesh;
   double *traj; /* walk_kernel_coop4_traj: [t - t_begin][3][n], the positions after every time step of the launch */
+  /* > 0: WALKER-major instead, [slot][traj_row_steps][x y z 0]: a walker's step is ONE 32-byte store into its own row.
+   * Runs whose phases come from recorded positions (more than four measurements on a mesh) use it: with per-lane
+   * clocks the lanes of a wavefront sit at different steps, three 8-byte stores per lane into three rows of the
+   * step-major layout cost the walk kernel a fifth of its rate (1.19e10 with them, 1.51e10 without, 1.35e10 this
+   * way: profiles/history/r04_ab_m32_recorded_positions_layout.txt) */
+  int traj_row_steps;
   /* recording for the caller (dsim_set_recording) while the walkers sit in sorted slots: slot i records into column
    * rec_col[i] - its walker's index - so that the recording comes out in walker order; nullptr: column i */
   const int32_t *rec_col;
@@ -654,8 +660,13 @@ DSD void walk_body(const WalkParams &p_arg) {
           r.y = __builtin_fma(step.y, sl, r.y);
           r.z = __builtin_fma(step.z, sl, r.z);
           if (TRAJ) {
-            double *q = p.traj + (int64_t)(t0 + k_lane - p.t_begin) * 3 * p.n + rec_i;
-            q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
+            if (p.traj_row_steps > 0) {
+              double *q = p.traj + ((int64_t)rec_i * p.traj_row_steps + (t0 + k_lane - p.t_begin)) * 4;
+              *reinterpret_cast<double4 *>(q) = make_double4(r.x, r.y, r.z, 0.0);
+            } else {
+              double *q = p.traj + (int64_t)(t0 + k_lane - p.t_begin) * 3 * p.n + rec_i;
+              q[0] = r.x, q[p.n] = r.y, q[2 * p.n] = r.z;
+            }
           }
           if (TRAJ) {
             /* phases are accumulated from the recorded positions */
@@ -850,8 +861,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int k = 0; k < steps; k++) {
     /* the next step's operands are on their way while this one's are used (the last step reads its own again) */
     const int kn = min(k + 1, steps - 1);
-    const double *qn = traj + (int64_t)kn * 3 * n + rec_i;
     const double *gn = gp + (int64_t)kn * M * 4; /* never beyond the last step: m0 + 31 <= M + 30 stays inside the padding */
+    const double *qn = traj + (int64_t)kn * 3 * n + rec_i;
     const double xn = qn[0], yn = qn[n], zn = qn[2 * n];
     const double2 axy_n = *reinterpret_cast<const double2 *>(gn);
     const double az_n = gn[2];
@@ -866,6 +877,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     x = xn, y = yn, z = zn;
     axy = axy_n, az = az_n, bxy = bxy_n, bz = bz_n;
+  }
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+      if (m < mc) phase[(int64_t)(m0 + m) * phase_stride + i] = ph[m];
+  }
+}
+
+/* The same accumulation from WALKER-major positions, rows[slot][row_steps][x y z 0] (WalkParams::traj_row_steps; row_steps
+ * even).  Read by its own lane a row costs a 32-byte request per lane and step - 64 cache lines per load instruction, and
+ * the address unit of the CU, not its SIMDs, sets the pace (measured: the whole job gains 3 % where the walk kernel gained
+ * 10 %).  So a wavefront fetches the rows of its 64 walkers TOGETHER, two steps (64 bytes of every row) at a time, straight
+ * into LDS (global_load_lds_dwordx4: four per chunk, each 16 rows x 64 bytes, no VGPRs in between), one chunk ahead of the
+ * arithmetic, and every lane then reads its own row out of LDS.  The 16-byte pieces of a row sit at position
+ * piece ^ ((row >> 1) & 3), which spreads the 64 lanes of a 16-byte read evenly over the banks.  4 KB per chunk, two chunks
+ * in flight per wavefront: 32 KB per workgroup - what phase_lds_reserve asked for without using it is now used. */
+#define PHASE_ROWS_LDS_PER_WAVE 8192
+template <int MB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void phase_from_rows_kernel(const double *rows, int64_t n, int steps, int row_steps,
+                                                                                                      const double *g4, int M, int m0, int mc, int t_first,
+                                                                                                      double gdt, double *phase, int64_t phase_stride) {
+  extern __shared__ __attribute__((aligned(16))) char stage[];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  char *buf = stage + wave * PHASE_ROWS_LDS_PER_WAVE;
+  const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < n;
+  const int64_t i = live ? i_raw : n - 1; /* every lane stays active (row broadcasts); surplus lanes redo the last walker and store nothing */
+  const int j = lane & 15;
+  double ph[MB];
+#pragma unroll
+  for (int m = 0; m < MB; m++) ph[m] = m < mc ? phase[(int64_t)(m0 + m) * phase_stride + i] : 0.0;
+  /* what this lane fetches for the wavefront: in fetch q (0..3) the piece `pos ^ ((r >> 1) & 3)` of row r = 16 q + lane / 4 */
+  const int64_t w0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+  const char *src[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int r = 16 * q + (lane >> 2), pos = lane & 3;
+    const int64_t slot = w0 + r < n ? w0 + r : n - 1;
+    src[q] = reinterpret_cast<const char *>(rows) + (slot * row_steps) * 32 + ((pos ^ ((r >> 1) & 3)) << 4);
+  }
+  auto fetch = [&](int c) { /* chunk c = steps 2c, 2c + 1 of the 64 rows -> buffer c & 1 */
+    char *dst = buf + (c & 1) * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[q] + (int64_t)c * 64),
+                                       (__attribute__((address_space(3))) void *)(dst + q * 1024), 16, 0, 0);
+  };
+  const int n_chunks = (steps + 1) >> 1;
+  fetch(0);
+  const double *gp = g4 + ((int64_t)t_first * M + m0 + j) * 4;
+  double2 axy = *reinterpret_cast<const double2 *>(gp), bxy = make_double2(0.0, 0.0);
+  double az = gp[2], bz = 0.0;
+  if (MB > 16) bxy = *reinterpret_cast<const double2 *>(gp + 64), bz = gp[66];
+  const int sw = (lane >> 1) & 3;
+  for (int c = 0; c < n_chunks; c++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* chunk c has landed in LDS (it was asked for a whole chunk of arithmetic ago) */
+    __builtin_amdgcn_wave_barrier();
+    if (c + 1 < n_chunks) fetch(c + 1);
+    const char *mine = buf + (c & 1) * 4096 + lane * 64;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int k = 2 * c + s2;
+      if (k < steps) { /* wave-uniform */
+        const double2 xy = *reinterpret_cast<const double2 *>(mine + (((2 * s2) ^ sw) << 4));
+        const double z = *reinterpret_cast<const double *>(mine + (((2 * s2 + 1) ^ sw) << 4));
+        const int kn = min(k + 1, steps - 1);
+        const double *gn = gp + (int64_t)kn * M * 4; /* never beyond the last step: m0 + 31 <= M + 30 stays inside the padding */
+        const double2 axy_n = *reinterpret_cast<const double2 *>(gn);
+        const double az_n = gn[2];
+        double2 bxy_n = make_double2(0.0, 0.0);
+        double bz_n = 0.0;
+        if (MB > 16) bxy_n = *reinterpret_cast<const double2 *>(gn + 64), bz_n = gn[66];
+        dpp_fence(axy.x, axy.y, az);
+        phase_step16<0, 0, MB>(ph, axy.x, axy.y, az, xy.x, xy.y, z, gdt);
+        if (MB > 16) {
+          dpp_fence(bxy.x, bxy.y, bz);
+          phase_step16<16, 0, MB>(ph, bxy.x, bxy.y, bz, xy.x, xy.y, z, gdt);
+        }
+        axy = axy_n, az = az_n, bxy = bxy_n, bz = bz_n;
+      }
+    }
   }
   if (live) {
 #pragma unroll
