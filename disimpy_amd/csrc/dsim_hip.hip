@@ -975,7 +975,7 @@ struct WalkGroup {
   int *ev_used = nullptr;
   unsigned long long *counters = nullptr; /* [2][4] on the device: see dsim_sim::counters */
   int launch_no = 0;                      /* launch k uses counter set k & 1 */
-  double *traj = nullptr;                 /* recorded mode: this group's [step][3][n] region of the handle's buffer */
+  double *traj = nullptr;                 /* recorded mode: this group's rows[slot][step][x y z 0] of the handle's buffer */
   int32_t t_pos = 0;                      /* recorded mode: the time step the group has reached */
   int32_t t_sorted = 0;                   /* recorded mode: the time step of the group's last re-sort */
   double clear_frac = -1;                 /* share of walkers in clear cells as of the last launch's sort (-1: unknown) */
