@@ -636,6 +636,11 @@ DSD void walk_body(const WalkParams &p_arg) {
       int k_lane = 0;
       if (p.tcur != nullptr && live) k_lane = p.tcur[i] - t0;
       bool in_step = false, clear = false;
+      /* one accumulator, gradient samples from global memory: the sample of a step is loaded when the step STARTS (6 VGPRs
+       * more: 125 of the 128) - loaded when the step ends it is needed at once, and the wavefront waited for it */
+      constexpr bool PREG = MB == 1 && GSRC == 1 && !TRAJ;
+      double2 gpre_xy = make_double2(0.0, 0.0);
+      double gpre_z = 0.0;
       V3 step = {0, 0, 0};
       double sl = 0;
       int64_t iter_idx = 0;
@@ -646,6 +651,11 @@ DSD void walk_body(const WalkParams &p_arg) {
         if (__ballot(want && (in_step || may_start)) == 0ULL) break;
         if (want && !in_step && may_start) {
           clear = walker_is_clear(p.mesh, r); /* look-ups issued before, consumed after the random step */
+          if (PREG) { /* the step's gradient sample, asked for now: it is needed when the step ends, one to several passes from here */
+            const double *g = p.g4 + ((int64_t)(t0 + k_lane) * p.M + p.m0) * 4;
+            gpre_xy = *reinterpret_cast<const double2 *>(g);
+            gpre_z = g[2];
+          }
           step = random_step(rng, log_tab, cos_tab);
           sl = p.step_l;
           iter_idx = 0;
@@ -679,6 +689,9 @@ DSD void walk_body(const WalkParams &p_arg) {
               double inner = __builtin_fma(gz, r.z, __builtin_fma(gxy.x, r.x, gxy.y * r.y));
               ph[m] = __builtin_fma(p.gdt, inner, ph[m]);
             }
+          } else if (PREG) {
+            double inner = __builtin_fma(gpre_z, r.z, __builtin_fma(gpre_xy.x, r.x, gpre_xy.y * r.y));
+            ph[0] = __builtin_fma(p.gdt, inner, ph[0]);
           } else {
             const double *g = p.g4 + ((int64_t)(t0 + k_lane) * p.M + p.m0) * 4;
 #pragma unroll
