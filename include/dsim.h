@@ -37,13 +37,17 @@
  *     abandoned like in the reference (simulations.py:478-479);
  *   - gradient: M >= 1, T >= 1, T * M * 32 bytes of device memory for the re-laid-out waveform.
  *
- * Environment.  The library reads four variables, all of them tuning switches for measurement runs - results never
- * depend on them (the GPU parity tests run with and without):
+ * Environment.  The library reads six variables, all of them tuning or diagnostic switches for measurement runs -
+ * results never depend on them (the GPU parity tests run with and without):
  *   DSIM_GROUPS=1..4      walker groups (streams) of a mesh run with per-walker clocks; default 2 from 2^18 walkers;
  *   DSIM_SORT_BITS=6..24  log2 of the Morton bins of the walker re-sort; default 18;
  *   DSIM_XCD_RUN=0..10    log2 of the consecutive walker groups (of 256) an XCD takes in turn; default 3;
  *   DSIM_MICRO=t1,t2,t3,t4,min_cell  thresholds of the fine grid (list length -> cells per subvoxel) and the smallest
- *                         cell in step lengths; default 2,4,16,2^30,1.5.
+ *                         cell in step lengths; default 2,4,16,2^30,1.5;
+ *   DSIM_PHASE_LDS=bytes  dynamic LDS the phase kernel of a recorded mesh run (more than four measurements) asks for
+ *                         beyond what it uses, so that its workgroups enter a CU only where a walk workgroup has
+ *                         retired; default: a rule on the walk kernel's own LDS (phase_lds_reserve);
+ *   DSIM_FILL_STATS=1     prints the shape of the mesh fill's bucket index on stderr when a fill session opens.
  * The Python binding adds DSIM_LIB=<path> (disimpy_amd/_lib.py): load another build of this library, e.g. an older
  * kernel for a same-box A/B; every symbol of this header must be there, or loading fails.
  */
