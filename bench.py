@@ -394,7 +394,7 @@ def kernel_name(sub, M, args):
     mb = 1 << max(0, (min(M, 32) - 1).bit_length())
     if sub.type != "mesh" or args.mesh_traversal == 1:
         return "walk_kernel<%s,%d>" % (sub.type, mb)
-    return "walk_kernel_coop4<%d>" % mb if mb <= 4 else "walk_kernel_coop4_traj + phase_from_traj_kernel<%d>" % mb
+    return "walk_kernel_coop4<%d>" % mb if mb <= 4 else "walk_kernel_coop4_traj + phase_from_rows_kernel<%d>" % mb
 
 
 def profile_entry(workload):

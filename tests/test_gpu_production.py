@@ -140,7 +140,7 @@ def test_two_walker_groups_with_ragged_halves_and_permeable_walls(lib, oracle_ex
 @pytest.mark.parametrize("groups", [1, 2, 3])
 def test_many_measurements_on_a_mesh_through_the_group_driver(lib, oracle_exact, monkeypatch, groups):
     """M = 5 and M = 40 on a mesh with re-sorted walkers: positions recorded per range of steps, phases added up from
-    them (phase_from_traj_kernel), one / two / three walker groups on their own streams with ragged sizes, two calls."""
+    them (phase_from_rows_kernel: walker-major rows staged through LDS), one / two / three walker groups on their own streams with ragged sizes, two calls."""
     from disimpy_amd import substrates
 
     m = golden("cylinder_mesh_closed.npz")
