@@ -77,6 +77,11 @@ struct MeshDev {
                                  cell_start is indexed by the subvoxel itself) */
   const uint32_t *cell_start; /* [n_cells + 1] the records of cells c .. c+r-1 (a run along z inside one subvoxel) are
                                  mrec[cell_start[c] .. cell_start[c + r]) */
+  /* [r5] lk > 0: the same table with a slot block for EVERY subvoxel, empty ones included (slot (s << (3 lk + 2)) + cell;
+   * an empty subvoxel's slots all hold the record count before it): the cooperative traversal finds a run's records
+   * with ONE level of look-ups instead of sv_base -> cell_start.  Built on the device from the two compact arrays
+   * (expand_cells_kernel); nullptr when the table would exceed DSIM_DENSE_CELLS_MB (the two-level path then) */
+  const uint32_t *cell_dense;
   const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
                               AABB (of the triangle's part inside the cell) rounded outward, float32 supporting
                               plane n.x = c, triangle index, position in the reference's list */
@@ -510,6 +515,22 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p_arg, con
   r0.x = __builtin_fma(step.x, step_l, r0.x);
   r0.y = __builtin_fma(step.y, step_l, r0.y);
   r0.z = __builtin_fma(step.z, step_l, r0.z);
+}
+
+/* the dense cell table of MeshDev::cell_dense from the compact one: entry (s << lcs) + c = cell_start[sv_base[s] + c], or - for
+ * an empty subvoxel - recs_before[s], the number of records of the subvoxels before s (= the first record of the next
+ * non-empty one: the table stays a CSR over all slots).  n_slots = n_sub << lcs; the last entry (the end of all records) too */
+__global__ void expand_cells_kernel(const int32_t *sv_base, const uint32_t *cell_start, const uint32_t *recs_before, int lcs,
+                                    uint64_t n_slots, uint32_t *dense) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_slots) return;
+  const uint64_t s = i >> lcs;
+  if (i == n_slots) {
+    dense[i] = recs_before[s];
+    return;
+  }
+  const int32_t base = sv_base[s];
+  dense[i] = base >= 0 ? cell_start[(uint32_t)base + (uint32_t)(i & ((1ull << lcs) - 1ull))] : recs_before[s];
 }
 
 #include "dsim_mesh_coop.h"

@@ -504,6 +504,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const int lk = ms.lk;
     const int lcs = 3 * lk + 2;                 /* log2 of the cell slots per subvoxel, lk > 0 */
     const unsigned cmask = (1u << lcs) - 1u;
+    const uint32_t *const dense = lk > 0 ? ms.cell_dense : nullptr;
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     /* two cursors: over the 64 first-run slots and over the named extra runs behind them.  A trip of stage 1c gives
      * every lane one of each - the extras are few (a box that straddles a subvoxel face: one walker in ten), so a trip
@@ -520,17 +521,23 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       if (e.x != 0xffffffffu) {
         STAT_LANE(5);
         STAT_WAVE(5);
-        int cell = (int)e.y;
-        bool some = true;
-        if (lk > 0) {
-          const int base = ms.sv_base[e.y >> lcs];
-          some = base >= 0;
-          cell = base + (int)(e.y & cmask);
-        }
-        if (some && !ABLATE(2)) {
-          const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
+        if (dense != nullptr) { /* one level: the run's slots in the table that has a block for every subvoxel (wave-uniform branch) */
+          const unsigned r0i = dense[e.y], r1i = dense[e.y + ((e.x >> 24) & 15u) + 1u];
           first = (int)r0i;
           cnt = (int)(r1i - r0i);
+        } else {
+          int cell = (int)e.y;
+          bool some = true;
+          if (lk > 0) {
+            const int base = ms.sv_base[e.y >> lcs];
+            some = base >= 0;
+            cell = base + (int)(e.y & cmask);
+          }
+          if (some && !ABLATE(2)) {
+            const unsigned r0i = ms.cell_start[cell], r1i = ms.cell_start[cell + (int)((e.x >> 24) & 15u) + 1];
+            first = (int)r0i;
+            cnt = (int)(r1i - r0i);
+          }
         }
       }
       return make_int2(first, cnt);

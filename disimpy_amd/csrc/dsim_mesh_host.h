@@ -47,6 +47,7 @@ struct DevMesh {
   float4 *mrec = nullptr;
   int32_t *sv_base = nullptr;
   uint32_t *cell_start = nullptr;
+  uint32_t *cell_dense = nullptr; /* lk > 0: a slot block for every subvoxel (MeshDev::cell_dense), or nullptr */
   int lk = 0; /* log2 of the fine cells per subvoxel and axis */
   int32_t *clear_idx = nullptr;
   uint32_t *clear_bits = nullptr;
@@ -71,6 +72,7 @@ static void free_mesh(DevMesh &m) {
   if (m.mrec) (void)hipFree(m.mrec);
   if (m.sv_base) (void)hipFree(m.sv_base);
   if (m.cell_start) (void)hipFree(m.cell_start);
+  if (m.cell_dense) (void)hipFree(m.cell_dense);
   if (m.clear_idx) (void)hipFree(m.clear_idx);
   if (m.clear_bits) (void)hipFree(m.clear_bits);
   if (m.bounds) (void)hipFree(m.bounds);
@@ -463,6 +465,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   std::vector<int32_t> sv_base((size_t)(lk > 0 ? n_sub : 1), -1);
   std::vector<uint32_t> cell_start;
   std::vector<float4> mrec;
+  std::vector<uint32_t> recs_before((size_t)(lk > 0 ? n_sub + 1 : 1), 0u); /* records of the subvoxels before s (dense table) */
   cell_start.reserve((size_t)(lk > 0 ? n_nonempty * slots : n_sub) + 1);
   {
     /* per non-empty subvoxel: the record count of every slot and the records, built by a few host threads (the subvoxels are
@@ -574,6 +577,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     }
     size_t tn = 0;
     for (int64_t s = 0; s < n_sub; s++) {
+      if (lk > 0) recs_before[(size_t)s] = (uint32_t)(mrec.size() / 3);
       if (ranges[s].y <= ranges[s].x) {
         if (lk == 0) cell_start.push_back((uint32_t)(mrec.size() / 3)); /* dense over the subvoxels: an empty range */
         continue;
@@ -589,6 +593,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     }
     if (mrec.size() / 3 >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
     cell_start.push_back((uint32_t)(mrec.size() / 3)); /* end of the last cell */
+    if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)(mrec.size() / 3);
     if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
   }
   if (host_only) { /* no device involved */
@@ -625,6 +630,28 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMemcpyAsync(dm.sv_base, sv_base.data(), sv_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(dm.cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   dm.lk = lk;
+  if (lk > 0 && step_l > 0) { /* (the fill session passes step_l = 0: it never walks the fine grid)
+     * [r5] the cooperative traversal's one-level table: a slot block for EVERY subvoxel (C5b: 125 000 subvoxels x 2 048
+     * slots x 4 bytes = 1 GB of which the 2 280 non-empty blocks are ever read; 288 GB of HBM per GPU afford it), expanded
+     * on the device from the compact arrays.  DSIM_DENSE_CELLS_MB caps it (default 4096, 0 = never: two-level look-ups) */
+    const int lcs = 3 * lk + 2;
+    const uint64_t n_slots = (uint64_t)n_sub << lcs;
+    double cap_mb = 4096;
+    if (const char *e = getenv("DSIM_DENSE_CELLS_MB")) cap_mb = atof(e);
+    if ((double)(n_slots + 1) * 4.0 <= cap_mb * 1048576.0) {
+      uint32_t *before_d = nullptr;
+      HIP_TRY(hipMalloc(&dm.cell_dense, (size_t)(n_slots + 1) * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&before_d, recs_before.size() * sizeof(uint32_t)));
+      hipError_t e = hipMemcpyAsync(before_d, recs_before.data(), recs_before.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) {
+        expand_cells_kernel<<<(unsigned)((n_slots + 256) / 256), 256, 0, stream>>>(dm.sv_base, dm.cell_start, before_d, lcs, n_slots, dm.cell_dense);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      (void)hipFree(before_d);
+      if (e != hipSuccess) return fail(DSIM_ERR_HIP, "dense cell table: %s", hipGetErrorString(e));
+    }
+  }
   HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
@@ -661,6 +688,7 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.mrec = dm.mrec;
   m.sv_base = dm.sv_base;
   m.cell_start = dm.cell_start;
+  m.cell_dense = dm.cell_dense;
   m.lk = dm.lk;
   m.bounds = dm.bounds;
   m.clear_idx = dm.clear_idx;
