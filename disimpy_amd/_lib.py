@@ -97,7 +97,8 @@ def load():
     lib.dsim_mesh_clearance_map.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, C.c_double,
                                             _i32p, C.POINTER(C.c_uint32), _i64p, _i32p]
     lib.dsim_mesh_fine_grid.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, C.c_double,
-                                        _i32p, _i64p, _i64p, _i32p, C.POINTER(C.c_uint32), _i32p, _i32p, C.POINTER(C.c_float)]
+                                        _i32p, _i64p, _i64p, _i32p, C.POINTER(C.c_uint32), _i32p, _i32p, C.POINTER(C.c_float),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     lib.dsim_triangle_box_overlap.argtypes = [_f64p, _f64p]
     lib.dsim_interval_sv_overlap.argtypes = [_f64p, C.c_int64, C.c_double, C.c_double, _i64p, _i64p]
     lib.dsim_last_run_ms.argtypes = [_h, _f64p, _i32p]
@@ -191,16 +192,19 @@ def mesh_fine_grid(vertices, faces, xs, ys, zs, n_sv, subvoxel_indices, triangle
     svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
     lk, nc, nr = C.c_int32(0), C.c_int64(0), C.c_int64(0)
     args = (p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri), len(tri), float(step_l))
-    check(lib.dsim_mesh_fine_grid(*args, C.byref(lk), C.byref(nc), C.byref(nr), None, None, None, None, None))
+    check(lib.dsim_mesh_fine_grid(*args, C.byref(lk), C.byref(nc), C.byref(nr), None, None, None, None, None, None, None))
     sv_base = np.full(int(np.prod(nsv)), -1, dtype=np.int32)
     cell_start = np.zeros(nc.value + 1, dtype=np.uint32)
     rt, rp = np.zeros(max(nr.value, 1), dtype=np.int32), np.zeros(max(nr.value, 1), dtype=np.int32)
     box = np.zeros((max(nr.value, 1), 6), dtype=np.float32)
+    packed = np.zeros((max(nr.value, 1), 8), dtype=np.uint32)
+    quantum = np.zeros(1, dtype=np.float32)
     check(lib.dsim_mesh_fine_grid(*args, C.byref(lk), C.byref(nc), C.byref(nr), sv_base.ctypes.data_as(_i32p),
                                   cell_start.ctypes.data_as(C.POINTER(C.c_uint32)), rt.ctypes.data_as(_i32p), rp.ctypes.data_as(_i32p),
-                                  box.ctypes.data_as(C.POINTER(C.c_float))))
+                                  box.ctypes.data_as(C.POINTER(C.c_float)), packed.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  quantum.ctypes.data_as(C.POINTER(C.c_float))))
     return dict(lk=lk.value, sv_base=sv_base if lk.value > 0 else None, cell_start=cell_start, tri=rt[: nr.value], pos=rp[: nr.value],
-                box=box[: nr.value])
+                box=box[: nr.value], packed=packed[: nr.value], quantum=float(quantum[0]))
 
 
 def triangle_box_overlap(triangle, box):

@@ -739,7 +739,7 @@ extern "C" int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, c
                                    const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
                                    const int64_t *triangle_indices, int64_t n_refs, double step_l, int32_t *log2_cells, int64_t *n_cells,
                                    int64_t *n_records, int32_t *sv_base, uint32_t *cell_start, int32_t *rec_triangle, int32_t *rec_position,
-                                   float *rec_box) {
+                                   float *rec_box, uint32_t *rec_packed, float *quantum) {
   if (!log2_cells || !n_cells || !n_records) return fail(DSIM_ERR_INVALID, "dsim_mesh_fine_grid: null argument");
   HostFineGrid fg;
   DevMesh none;
@@ -751,14 +751,16 @@ extern "C" int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, c
     if (sv_base && fg.lk > 0) memcpy(sv_base, fg.sv_base.data(), fg.sv_base.size() * sizeof(int32_t));
     memcpy(cell_start, fg.cell_start.data(), fg.cell_start.size() * sizeof(uint32_t));
     for (int64_t r = 0; r < recs; r++) {
-      const float4 q0 = fg.mrec[3 * r], q1 = fg.mrec[3 * r + 1], q2 = fg.mrec[3 * r + 2];
-      if (rec_triangle) memcpy(&rec_triangle[r], &q2.z, 4);
-      if (rec_position) memcpy(&rec_position[r], &q2.w, 4);
+      const HostRecord &q = fg.recs[(size_t)r];
+      if (rec_triangle) rec_triangle[r] = q.tri;
+      if (rec_position) rec_position[r] = q.pos;
       if (rec_box) {
-        const float b[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}; /* min x y z, max x y z */
+        const float b[6] = {q.lo[0], q.lo[1], q.lo[2], q.hi[0], q.hi[1], q.hi[2]}; /* min x y z, max x y z */
         memcpy(rec_box + 6 * r, b, sizeof(b));
       }
+      if (rec_packed) memcpy(rec_packed + 8 * r, &fg.mrec[2 * (size_t)r], 32);
     }
+    if (quantum) *quantum = fg.qs;
   }
   *log2_cells = fg.lk;
   *n_cells = cells;

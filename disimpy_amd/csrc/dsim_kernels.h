@@ -61,6 +61,12 @@ __device__ int dsim_ablate = 0;
 #define ABLATE(n) false
 #endif
 
+/* native vectors: a load of one is ONE instruction of that width (HIP's uint4 / float2 are structs of scalars that the
+ * compiler takes apart and regroups as it sees fit - the 32-byte records came back as 12 + 16 (misaligned) + 4 bytes) */
+typedef unsigned ds_uint4 __attribute__((ext_vector_type(4)));
+typedef float ds_float2 __attribute__((ext_vector_type(2)));
+typedef short ds_short2 __attribute__((ext_vector_type(2)));
+
 enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };
 
 #define DS_TRI_STRIDE 12 /* doubles per triangle record */
@@ -82,9 +88,21 @@ struct MeshDev {
    * with ONE level of look-ups instead of sv_base -> cell_start.  Built on the device from the two compact arrays
    * (expand_cells_kernel); nullptr when the table would exceed DSIM_DENSE_CELLS_MB (the two-level path then) */
   const uint32_t *cell_dense;
-  const float4 *mrec;      /* [n_mrec][3]   {minx miny minz maxx} {maxy maxz nx ny} {nz c tri csr_pos}: float32
-                              AABB (of the triangle's part inside the cell) rounded outward, float32 supporting
-                              plane n.x = c, triangle index, position in the reference's list */
+  /* [r5] 32-byte records, two 16-byte loads each (rounds 2-4: 48 bytes, three loads, float32 boxes):
+   *   [0] = {lo_x | lo_y << 16,  lo_z | nhi_x << 16,  nhi_y | nhi_z << 16,  triangle}
+   *   [1] = {nx, ny, nz, c}   float32 supporting plane n.x = c of the triangle
+   * The box - of the triangle's part inside the cell - in 15-bit fixed point: coordinate x -> x * qs with ONE scale for the
+   * three axes, qs = 32767 / (the largest of xs[nx], ys[ny], zs[nz]) - the reference's grids start at 0
+   * (substrates.py:506-508), so the voxel maps into [0, 32767]; lo rounded down, hi rounded up and stored as
+   * nhi = 32767 - hi, all clamped into [0, 32767] (a grid handed in through the C ABI that lies elsewhere clamps and is
+   * culled by the plane test alone - slower, never wrong).  A segment's box comes in the same form,
+   * {hi_x | hi_y << 16, hi_z | nlo_x << 16, nlo_y | nlo_z << 16} with nlo = 32767 - lo (quantise_box): the boxes overlap
+   * iff no 16-bit half of the three packed differences box - record is negative (three v_pk_sub_i16, one v_or3, one
+   * v_and).  Rounding outwards on both sides and clamping are monotone, so an overlap of the float32 boxes is never lost:
+   * what passes is a superset of what passed the float32 comparison, looser by up to 2 quanta (6.8 nm on the neuron's
+   * 223 um voxel, cells of 0.5 um) per side */
+  const ds_uint4 *mrec;
+  float qs;
   int lk;
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
   /* clearance map (dsim_hip.hip, build_clearance_map): every subvoxel is cut into F^3 fine cells, F = 1 << clear_lf;
@@ -236,17 +254,62 @@ DSD V3 load_v3(const double *p) {
  * ~8 ulp of the largest coordinate).  Only the seven numbers travel between lanes. */
 struct CullBox {
   float lox, loy, loz, hix, hiy, hiz;
-  float mx, my, mz, hx, hy, hz; /* midpoint and half vector of the segment in float32 */
+  ds_float2 mhx, mhy, mhz;      /* {midpoint, half vector} of the segment per axis, float32 (pairs: the plane test runs packed) */
   float tau;                    /* box and plane-side margin */
+};
+struct QBox { /* the box in the records' fixed point (quantise_box) */
+  unsigned b0, b1, b2;
 };
 
 DSD void box_from_segment(CullBox &c) {
-  const float ex = __builtin_fabsf(c.hx) + c.tau, ey = __builtin_fabsf(c.hy) + c.tau, ez = __builtin_fabsf(c.hz) + c.tau;
-  c.lox = c.mx - ex, c.hix = c.mx + ex;
-  c.loy = c.my - ey, c.hiy = c.my + ey;
-  c.loz = c.mz - ez, c.hiz = c.mz + ez;
+  const float ex = __builtin_fabsf(c.mhx.y) + c.tau, ey = __builtin_fabsf(c.mhy.y) + c.tau, ez = __builtin_fabsf(c.mhz.y) + c.tau;
+  c.lox = c.mhx.x - ex, c.hix = c.mhx.x + ex;
+  c.loy = c.mhy.x - ey, c.hiy = c.mhy.x + ey;
+  c.loz = c.mhz.x - ez, c.hiz = c.mhz.x + ez;
 }
 
+DSD unsigned pk_i16(int a, int b) { /* both saturated into [0, 32767] and packed a | b << 16 */
+  const ds_short2 p = __builtin_amdgcn_cvt_pk_i16(a, b); /* v_cvt_pk_i16_i32: signed saturation */
+  const ds_short2 z = {0, 0};
+  const ds_short2 m = __builtin_elementwise_max(p, z);   /* v_pk_max_i16 */
+  return __builtin_bit_cast(unsigned, m);
+}
+
+/* the float32 box of c in the records' fixed point (MeshDev::mrec): hi = ceil, lo = floor of x * qs, both by
+ * truncation of a value pushed up by 1.001 quanta (the float -> int conversion truncates, saturates and sends NaN to 0;
+ * a result that is one quantum too wide only keeps a record the exact box would have dropped).  18 VALU operations. */
+DSD QBox quantise_box(const CullBox &c, const MeshDev &ms) {
+  const float qs = ms.qs, up = 1.001f, top = 32767.0f + 1.001f;
+  const int hx = (int)__builtin_fmaf(c.hix, qs, up), hy = (int)__builtin_fmaf(c.hiy, qs, up), hz = (int)__builtin_fmaf(c.hiz, qs, up);
+  const int lx = (int)__builtin_fmaf(-c.lox, qs, top), ly = (int)__builtin_fmaf(-c.loy, qs, top), lz = (int)__builtin_fmaf(-c.loz, qs, top);
+  QBox q;
+  q.b0 = pk_i16(hx, hy);
+  q.b1 = pk_i16(hz, lx);
+  q.b2 = pk_i16(ly, lz);
+  return q;
+}
+
+/* Can the record be skipped?  No when (a) no 16-bit half of the three packed differences box - record is negative (the
+ * fixed-point boxes overlap) and (b) the segment does not lie wholly on one side of the triangle's plane: with the midpoint
+ * m and the half vector h of the segment the end points evaluate to (n.m - c) -+ n.h, so both are beyond the margin tau on
+ * the same side iff |n.m - c| - |n.h| > tau.  mh_x = {m.x, h.x} etc.: the two dot products run as three packed
+ * operations.  Every rounding / flush-to-zero / NaN case falls on the "keep" side or concerns a walker whose fp64 test
+ * cannot hit anyway (a NaN box quantises to an empty one). */
+DSD bool record_survives(const ds_uint4 &q0, const ds_uint4 &q1, unsigned b0, unsigned b1, unsigned b2, const ds_float2 &mh_x,
+                         const ds_float2 &mh_y, const ds_float2 &mh_z, float tau) {
+  /* (elements copied out first: __builtin_bit_cast applied to a vector ELEMENT, `q0.y`, reads element 0 with this compiler) */
+  const unsigned rx = q0.x, ry = q0.y, rz = q0.z;
+  const ds_short2 d0 = __builtin_bit_cast(ds_short2, b0) - __builtin_bit_cast(ds_short2, rx);
+  const ds_short2 d1 = __builtin_bit_cast(ds_short2, b1) - __builtin_bit_cast(ds_short2, ry);
+  const ds_short2 d2 = __builtin_bit_cast(ds_short2, b2) - __builtin_bit_cast(ds_short2, rz);
+  const unsigned neg = (__builtin_bit_cast(unsigned, d0) | __builtin_bit_cast(unsigned, d1) | __builtin_bit_cast(unsigned, d2)) & 0x80008000u;
+  const float nx = __uint_as_float(q1.x), ny = __uint_as_float(q1.y), nz = __uint_as_float(q1.z), pc = __uint_as_float(q1.w);
+  ds_float2 t = (ds_float2){ny, ny} * mh_y;
+  t = __builtin_elementwise_fma((ds_float2){nx, nx}, mh_x, t);
+  t = __builtin_elementwise_fma((ds_float2){nz, nz}, mh_z, t); /* {n.m, n.h} */
+  const float side = __builtin_fabsf(t.x - pc) - __builtin_fabsf(t.y);
+  return neg == 0u && side <= tau;
+}
 DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   /* float32 arithmetic from the start: start point and direction rounded once (half an ulp each), the midpoint one
    * more rounding - about one ulp of the largest coordinate in all, against a margin of sixteen */
@@ -254,12 +317,12 @@ DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   const float sx = (float)step.x, sy = (float)step.y, sz = (float)step.z;
   const float sl = (float)step_l, hl = 0.5f * sl;
   CullBox c;
-  c.hx = sx * hl;
-  c.hy = sy * hl;
-  c.hz = sz * hl;
-  c.mx = ax + c.hx;
-  c.my = ay + c.hy;
-  c.mz = az + c.hz;
+  c.mhx.y = sx * hl;
+  c.mhy.y = sy * hl;
+  c.mhz.y = sz * hl;
+  c.mhx.x = ax + c.mhx.y;
+  c.mhy.x = ay + c.mhy.y;
+  c.mhz.x = az + c.mhz.y;
   /* magnitude of the largest coordinate of either end point: |a| + step_l bounds both (|step| = 1) */
   const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az)) + sl;
   c.tau = __builtin_fmaf(2.0001e-6f, big, 1.0001e-6f * sl);
@@ -348,35 +411,32 @@ DSD void iteration_serial(const MeshDev &ms, const SubvoxelWalk &w, const V3 &r0
  * the reference keeps the one its loops meet first (strict <, simulations.py:981) - is only
  * detected here (`tie`); the caller then redoes the pass in the reference's order.  The same
  * triangle met again (another cell, another subvoxel of the same image) returns the same d. */
-DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &cb, const V3 &tr0, const V3 &step,
+DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &cb, const QBox &qb, const V3 &tr0, const V3 &step,
                          double &min_d, int &closest, bool &tie) {
+  const ds_float2 mh_x = cb.mhx, mh_y = cb.mhy, mh_z = cb.mhz;
+  const float tau = cb.tau;
+  const unsigned b0 = qb.b0, b1 = qb.b1, b2 = qb.b2;
   for (int i = begin; i < end; i += 4) {
     STAT_LANE(4);
     STAT_WAVE(4);
-    float4 q0[4], q1[4], q2[4];
+    ds_uint4 q0[4], q1[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int j = min(i + u, end - 1);
-      q0[u] = ms.mrec[3 * j];
-      q1[u] = ms.mrec[3 * j + 1];
-      q2[u] = ms.mrec[3 * j + 2];
+      q0[u] = ms.mrec[2 * j];
+      q1[u] = ms.mrec[2 * j + 1];
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (i + u >= end) break;
       STAT_LANE(5);
-      /* (1) AABB of the triangle vs cull box of the segment */
-      if (q0[u].x > cb.hix || q0[u].w < cb.lox || q0[u].y > cb.hiy || q1[u].x < cb.loy || q0[u].z > cb.hiz ||
-          q1[u].y < cb.loz)
-        continue;
-      /* (2) both end points strictly on one side of the triangle's plane (margin tau): the
-       * ray cannot meet the plane at 0 < d <= step_l.  Degenerate triangles have n = 0. */
-      const float sm = __builtin_fmaf(q2[u].x, cb.mz, __builtin_fmaf(q1[u].z, cb.mx, q1[u].w * cb.my)) - q2[u].y;
-      const float sh = __builtin_fmaf(q2[u].x, cb.hz, __builtin_fmaf(q1[u].z, cb.hx, q1[u].w * cb.hy));
-      if (__builtin_fabsf(sm) - __builtin_fabsf(sh) > cb.tau) continue;
+      /* (1) box of the triangle's part inside the cell vs cull box of the segment, (2) both end points strictly on one
+       * side of the triangle's plane (margin tau): the ray cannot meet the plane at 0 < d <= step_l.  Degenerate
+       * triangles have n = 0. */
+      if (!record_survives(q0[u], q1[u], b0, b1, b2, mh_x, mh_y, mh_z, tau)) continue;
       STAT_LANE(6);
       STAT_WAVE(6);
-      int ti = __float_as_int(q2[u].z);
+      int ti = (int)q0[u].w;
       const double *rec = ms.tri + (int64_t)ti * DS_TRI_STRIDE;
       double d = ray_triangle_intersection_check(load_v3(rec), load_v3(rec + 3), load_v3(rec + 6), tr0, step);
       if (d > 0) {
@@ -455,10 +515,11 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p_arg, con
         STAT_WAVE(2);
         V3 tr0 = {r0.x - shx, r0.y - shy, r0.z - shz};
         const CullBox cb = make_cull_box(tr0, step, step_l);
+        const QBox qb = quantise_box(cb, ms);
         if (lk == 0) {
           STAT_LANE(3);
           STAT_WAVE(3);
-          scan_candidates(ms, (int)ms.cell_start[base], (int)ms.cell_start[base + 1], cb, tr0, step, min_d, closest, tie);
+          scan_candidates(ms, (int)ms.cell_start[base], (int)ms.cell_start[base + 1], cb, qb, tr0, step, min_d, closest, tie);
         } else {
           /* x, y: 2k half-cell units per subvoxel, a cell of two units at every unit but the last (dsim_mesh_host.h):
            * the units u0 .. u1 of the box are covered by the cells at u0, u0 + 2, ... */
@@ -471,7 +532,7 @@ DSD void step_mesh(V3 &r0, V3 &step, double step_l, const WalkParams &p_arg, con
             STAT_LANE(3);
             STAT_WAVE(3);
             const int c = base + (min(a, k2 - 2) * k2 + min(b, k2 - 2)) * k; /* the cells c0 .. c1 of this column: one run of records */
-            scan_candidates(ms, (int)ms.cell_start[c + c0], (int)ms.cell_start[c + c1 + 1], cb, tr0, step, min_d, closest, tie);
+            scan_candidates(ms, (int)ms.cell_start[c + c0], (int)ms.cell_start[c + c1 + 1], cb, qb, tr0, step, min_d, closest, tie);
             if (b + 1 < b1) {
               b += 2;
             } else if (a + 1 < a1) {

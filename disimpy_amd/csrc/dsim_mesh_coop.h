@@ -120,29 +120,14 @@ DSD CullBox shift_cull_box(const CullBox &c, double shx, double shy, double shz)
   if (shx == 0 && shy == 0 && shz == 0) return c;
   const float sx = (float)shx, sy = (float)shy, sz = (float)shz;
   CullBox o = c;
-  o.mx = c.mx - sx;
-  o.my = c.my - sy;
-  o.mz = c.mz - sz;
+  o.mhx.x = c.mhx.x - sx;
+  o.mhy.x = c.mhy.x - sy;
+  o.mhz.x = c.mhz.x - sz;
   /* rounding of the shifts and of the three subtractions: a few float32 ulps of the larger operand each */
-  o.tau = c.tau + 2e-6f * (__builtin_fabsf(sx) + __builtin_fabsf(sy) + __builtin_fabsf(sz) + __builtin_fabsf(c.mx) +
-                           __builtin_fabsf(c.my) + __builtin_fabsf(c.mz));
+  o.tau = c.tau + 2e-6f * (__builtin_fabsf(sx) + __builtin_fabsf(sy) + __builtin_fabsf(sz) + __builtin_fabsf(c.mhx.x) +
+                           __builtin_fabsf(c.mhy.x) + __builtin_fabsf(c.mhz.x));
   box_from_segment(o);
   return o;
-}
-
-/* > 0 when the record can be skipped - ONE number, no branches or mask arithmetic: the max over (a) the six box
- * gaps (a positive gap on any axis separates the triangle's box from the segment's) and (b) how far beyond the
- * margin tau the whole segment lies on one side of the triangle's plane: with the midpoint m and the half vector
- * h of the segment, the end points evaluate to (n.m - c) -+ n.h, so both are beyond tau on the same side iff
- * |n.m - c| - |n.h| > tau.  Every rounding / flush-to-zero / NaN case falls on the "keep" side or concerns a
- * walker whose fp64 test cannot hit anyway. */
-DSD float cull_margin(const float4 &q0, const float4 &q1, const float4 &q2, const CullBox &cb) {
-  const float g1 = __builtin_fmaxf(__builtin_fmaxf(q0.x - cb.hix, q0.y - cb.hiy), q0.z - cb.hiz);
-  const float g2 = __builtin_fmaxf(__builtin_fmaxf(cb.lox - q0.w, cb.loy - q1.x), cb.loz - q1.y);
-  const float sm = __builtin_fmaf(q2.x, cb.mz, __builtin_fmaf(q1.z, cb.mx, __builtin_fmaf(q1.w, cb.my, -q2.y)));
-  const float sh = __builtin_fmaf(q2.x, cb.hz, __builtin_fmaf(q1.z, cb.hx, q1.w * cb.hy));
-  const float side = (__builtin_fabsf(sm) - __builtin_fabsf(sh)) - cb.tau;
-  return __builtin_fmaxf(__builtin_fmaxf(g1, g2), side);
 }
 
 /* the fine grid coordinates of a pass, any periodic image, both ends inclusive, already clamped into the first / last
@@ -445,7 +430,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   /* ---- stage 1: owners work out their cull box and list the runs of fine cells their segment touches.  Box and
    * ray stay in the owner's registers (cb0, r0, step: unchanged until stage 4); the other lanes read
    * them with __shfl, so every lane has to be active wherever a shuffle is executed. */
-  CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, 0.0f};
+  QBox qb0 = {0u, 0u, 0u};
   int n_runs = 0;
   RunPlan rp = {0, 0, 0, 0, 0, 1, 1, 0, 0};
   const MeshDev &ms = p.mesh;
@@ -456,6 +442,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     SubvoxelWalk sw;
     FineRange fr;
     segment_query(ms, r0, step, step_l, xs, ys, zs, sw, cb0, fr);
+    qb0 = quantise_box(cb0, ms);
     n_runs = plan_runs(ms, sw, fr, rp);
     serial = n_runs < 0;
     n_runs = max(n_runs, 0);
@@ -613,61 +600,69 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const bool valid = idx < n_items;
         uint2 it = make_uint2(0u, 0u);
         if (valid) it = W->items[idx];
-        /* the records first: their addresses only need the item, so the 12 loads are in flight while the owner's
+        /* the records first: their addresses only need the item, so the 8 loads are in flight while the owner's
          * segment comes through the shuffles (a lane without an item reads record 0) */
         const int first_rec = valid ? (int)(it.x & 0x3fffffffu) : 0, cnt = valid ? (int)(it.x >> 30) + 1 : 1;
-        float4 q0[4], q1[4], q2[4];
+        ds_uint4 q0[4], q1[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
-          q0[u] = ms.mrec[3 * j];
-          q1[u] = ms.mrec[3 * j + 1];
-          q2[u] = ms.mrec[3 * j + 2];
+          q0[u] = ms.mrec[2 * j];
+          q1[u] = ms.mrec[2 * j + 1];
         }
         const int owner = (int)(it.y & 63u);
-        CullBox cb;
-        cb.mx = __shfl(cb0.mx, owner, 64), cb.my = __shfl(cb0.my, owner, 64), cb.mz = __shfl(cb0.mz, owner, 64);
-        cb.hx = __shfl(cb0.hx, owner, 64), cb.hy = __shfl(cb0.hy, owner, 64), cb.hz = __shfl(cb0.hz, owner, 64);
-        cb.tau = __shfl(cb0.tau, owner, 64);
-        box_from_segment(cb);
+        /* the owner's segment (plane test: midpoint and half vector as the pairs {m, h} per axis) and its box in the
+         * records' fixed point: ten dwords; the float32 box itself is only rebuilt for a periodic image */
+        ds_float2 mh_x = {__shfl(cb0.mhx.x, owner, 64), __shfl(cb0.mhx.y, owner, 64)};
+        ds_float2 mh_y = {__shfl(cb0.mhy.x, owner, 64), __shfl(cb0.mhy.y, owner, 64)};
+        ds_float2 mh_z = {__shfl(cb0.mhz.x, owner, 64), __shfl(cb0.mhz.y, owner, 64)};
+        float tau = __shfl(cb0.tau, owner, 64);
+        unsigned b0 = (unsigned)__shfl((int)qb0.b0, owner, 64), b1 = (unsigned)__shfl((int)qb0.b1, owner, 64);
+        unsigned b2 = (unsigned)__shfl((int)qb0.b2, owner, 64);
         if (valid) {
           STAT_LANE(4);
           STAT_WAVE(4);
         }
         if (valid && (it.y >> 6) != COOP_NO_SHIFT) { /* periodic image: move the box into its frame */
           const int snx = (int)((it.y >> 6) & 63u) - 32, sny = (int)((it.y >> 12) & 63u) - 32, snz = (int)((it.y >> 18) & 63u) - 32;
+          CullBox cb;
+          cb.mhx = mh_x, cb.mhy = mh_y, cb.mhz = mh_z, cb.tau = tau;
+          box_from_segment(cb);
           cb = shift_cull_box(cb, (double)snx * Lx, (double)sny * Ly, (double)snz * Lz);
+          const QBox qb = quantise_box(cb, ms);
+          mh_x.x = cb.mhx.x, mh_y.x = cb.mhy.x, mh_z.x = cb.mhz.x, tau = cb.tau;
+          b0 = qb.b0, b1 = qb.b1, b2 = qb.b2;
         }
         /* the four tests without a branch between or around them (with 64 lanes x 4 records somebody always passes
-         * the box, so a branch only costs mask juggling); a lane without an item tests record 0 for nothing */
-        unsigned alive_w = 0; /* this lane's survivors of the trip */
-#pragma unroll
-        for (int u = 0; u < 4; u++) alive_w |= (cull_margin(q0[u], q1[u], q2[u], cb) <= 0.0f ? 1u : 0u) << u;
-        alive_w &= (1u << cnt) - 1u; /* slots beyond the item's count repeat its last record (loads stay unconditional) */
-        if (!valid || ABLATE(3) || ABLATE(4)) alive_w = 0;
-        const float tz[4] = {q2[0].z, q2[1].z, q2[2].z, q2[3].z};
+         * the box, so a branch only costs mask juggling); a lane without an item tests record 0 for nothing.  Slots beyond
+         * the item's count repeat its last record (loads stay unconditional) and do not count.  The results never become
+         * a per-lane word: a comparison IS the wave's ballot of it */
+        const bool on = valid && !ABLATE(3) && !ABLATE(4);
+        const bool s0 = record_survives(q0[0], q1[0], b0, b1, b2, mh_x, mh_y, mh_z, tau), s1 = record_survives(q0[1], q1[1], b0, b1, b2, mh_x, mh_y, mh_z, tau);
+        const bool s2 = record_survives(q0[2], q1[2], b0, b1, b2, mh_x, mh_y, mh_z, tau), s3 = record_survives(q0[3], q1[3], b0, b1, b2, mh_x, mh_y, mh_z, tau);
+        const bool a0 = on & s0, a1 = on & (cnt > 1) & s1, a2 = on & (cnt > 2) & s2, a3 = on & (cnt > 3) & s3; /* & not &&: no branches */
         { /* the survivors' slots from four ballots (survivors in lower lanes first): the pool's fill level stays in a
            * scalar register, there is no LDS atomic to wait for and no counter to read back before the flush check
            * (round 2 / early round 3: one LDS atomic per lane and an LDS read per trip; C5b +1.4 %, C4 +1.7 %) */
-          const unsigned long long b0 = __ballot((alive_w & 1u) != 0), b1 = __ballot((alive_w & 2u) != 0);
-          const unsigned long long b2 = __ballot((alive_w & 4u) != 0), b3 = __ballot((alive_w & 8u) != 0);
-          if ((b0 | b1 | b2 | b3) != 0ULL) {
-            unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
-            below = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, below));
-            below = __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, below));
-            below = __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, below));
+          const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1), m2 = __ballot(a2), m3 = __ballot(a3);
+          if ((m0 | m1 | m2 | m3) != 0ULL) {
+            unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+            below = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, below));
+            below = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, below));
+            below = __builtin_amdgcn_mbcnt_hi((unsigned)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m3, below));
             int slot = n_surv + (int)below;
+            const bool alive[4] = {a0, a1, a2, a3};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-              if (!(alive_w >> u & 1u)) continue;
+              if (!alive[u]) continue;
               if (slot < COOP_SURV_CAP) {
-                W->surv_tri[slot] = (unsigned)__float_as_int(tz[u]);
+                W->surv_tri[slot] = q0[u].w;
                 W->surv_tag[slot] = it.y;
               } else
                 W->overflow[owner] = 1;
               slot++;
             }
-            n_surv = min(n_surv + (int)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3)), COOP_SURV_CAP);
+            n_surv = min(n_surv + (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)), COOP_SURV_CAP);
           }
         }
         T_MARK(W, lane, 4);

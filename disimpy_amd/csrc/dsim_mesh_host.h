@@ -44,7 +44,8 @@ struct DevMesh {
   double *tri = nullptr;
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
-  float4 *mrec = nullptr;
+  ds_uint4 *mrec = nullptr;
+  float qs = 0; /* fixed point of the record boxes: x -> x * qs (MeshDev) */
   int32_t *sv_base = nullptr;
   uint32_t *cell_start = nullptr;
   uint32_t *cell_dense = nullptr; /* lk > 0: a slot block for every subvoxel (MeshDev::cell_dense), or nullptr */
@@ -335,12 +336,53 @@ static bool clipped_triangle_box(const double *const tv[3], const double org[3],
   return true;
 }
 
+/* a record of the fine grid before it is packed: float32 box {min x y z, max x y z} of the triangle's part inside the
+ * cell, float32 supporting plane n.x = c, triangle, position in the reference's list */
+struct HostRecord {
+  float lo[3], hi[3];
+  float n[3], c;
+  int32_t tri, pos;
+};
+
+/* fixed point of the record boxes (MeshDev::mrec): quanta per metre as the FLOAT32 constant the kernels use */
+static float record_quantum(const double *const b3[3], const int64_t n_sv[3]) {
+  double far = 0;
+  for (int k = 0; k < 3; k++) far = std::max(far, b3[k][n_sv[k]]);
+  const float qs = far > 0 && std::isfinite(far) ? (float)(32767.0 / far) : 0.0f;
+  return std::isfinite(qs) ? qs : 0.0f; /* 0: every box becomes [0, 0] and nothing is culled by it */
+}
+
+/* 32-byte device records from the float32 ones: lo rounded down, hi rounded up in the EXACT value of x * qs (double
+ * arithmetic on the float32 constant; 1e-6 quanta of slack for its own rounding), clamped into [0, 32767] */
+static void pack_records(const std::vector<HostRecord> &recs, float qs, std::vector<uint4> &out) {
+  out.resize(std::max<size_t>(recs.size(), 1) * 2, make_uint4(0u, 0u, 0u, 0u));
+  auto q = [&](float x, bool up) -> uint32_t {
+    const double v = (double)x * (double)qs;
+    double r = up ? std::ceil(v + 1e-6) : std::floor(v - 1e-6);
+    if (!(r >= 0.0)) r = 0.0; /* NaN too */
+    if (r > 32767.0) r = 32767.0;
+    return (uint32_t)r;
+  };
+  for (size_t i = 0; i < recs.size(); i++) {
+    const HostRecord &r = recs[i];
+    const uint32_t lx = q(r.lo[0], false), ly = q(r.lo[1], false), lz = q(r.lo[2], false);
+    const uint32_t hx = 32767u - q(r.hi[0], true), hy = 32767u - q(r.hi[1], true), hz = 32767u - q(r.hi[2], true);
+    uint32_t nb[4];
+    memcpy(nb, r.n, 12);
+    memcpy(nb + 3, &r.c, 4);
+    out[2 * i] = make_uint4(lx | (ly << 16), lz | (hx << 16), hy | (hz << 16), (uint32_t)r.tri);
+    out[2 * i + 1] = make_uint4(nb[0], nb[1], nb[2], nb[3]);
+  }
+}
+
 /* the fine grid as built on the host (dsim_mesh_fine_grid hands it out so that its completeness can be tested without a GPU) */
 struct HostFineGrid {
   int lk = 0;
   std::vector<int32_t> sv_base;
   std::vector<uint32_t> cell_start;
-  std::vector<float4> mrec;
+  std::vector<HostRecord> recs;
+  std::vector<uint4> mrec; /* recs as the device gets them */
+  float qs = 0;
 };
 
 static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
@@ -464,7 +506,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   const size_t slots = (size_t)nun[0] * nun[1] * nun[2];
   std::vector<int32_t> sv_base((size_t)(lk > 0 ? n_sub : 1), -1);
   std::vector<uint32_t> cell_start;
-  std::vector<float4> mrec;
+  std::vector<HostRecord> mrec;
   std::vector<uint32_t> recs_before((size_t)(lk > 0 ? n_sub + 1 : 1), 0u); /* records of the subvoxels before s (dense table) */
   cell_start.reserve((size_t)(lk > 0 ? n_nonempty * slots : n_sub) + 1);
   {
@@ -472,7 +514,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
      * independent), then strung together in subvoxel order */
     struct Built {
       std::vector<uint32_t> count; /* [slots] */
-      std::vector<float4> recs;
+      std::vector<HostRecord> recs;
     };
     std::vector<int64_t> todo;
     for (int64_t s = 0; s < n_sub; s++)
@@ -533,10 +575,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
                 hi[ax] = std::min(hi[ax], h2);
               }
           }
-          float idx_bits, pos_bits;
           int32_t ti = refs[i];
-          memcpy(&idx_bits, &ti, sizeof(float));
-          memcpy(&pos_bits, &i, sizeof(float));
           /* supporting plane n.x = c in float32 (unit normal; c from the ROUNDED normal so that the
            * float32 plane is self-consistent); a degenerate triangle gets n = 0, c = 0 and is never culled */
           const double *r = &rec[(size_t)ti * DS_TRI_STRIDE];
@@ -549,9 +588,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
             fz = (float)(nz / nn);
             fc = (float)((double)fx * r[0] + (double)fy * r[1] + (double)fz * r[2]);
           }
-          out.recs.push_back(make_float4(lo[0], lo[1], lo[2], hi[0]));
-          out.recs.push_back(make_float4(hi[1], hi[2], fx, fy));
-          out.recs.push_back(make_float4(fz, fc, idx_bits, pos_bits));
+          out.recs.push_back(HostRecord{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}, {fx, fy, fz}, fc, ti, i});
         }
       }
     };
@@ -577,30 +614,38 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     }
     size_t tn = 0;
     for (int64_t s = 0; s < n_sub; s++) {
-      if (lk > 0) recs_before[(size_t)s] = (uint32_t)(mrec.size() / 3);
+      if (lk > 0) recs_before[(size_t)s] = (uint32_t)mrec.size();
       if (ranges[s].y <= ranges[s].x) {
-        if (lk == 0) cell_start.push_back((uint32_t)(mrec.size() / 3)); /* dense over the subvoxels: an empty range */
+        if (lk == 0) cell_start.push_back((uint32_t)mrec.size()); /* dense over the subvoxels: an empty range */
         continue;
       }
       const Built &bu = built[tn++];
       if (lk > 0) sv_base[s] = (int32_t)cell_start.size();
-      uint32_t at = (uint32_t)(mrec.size() / 3);
+      uint32_t at = (uint32_t)mrec.size();
       for (size_t ci = 0; ci < slots; ci++) {
         cell_start.push_back(at);
         at += bu.count[ci];
       }
       mrec.insert(mrec.end(), bu.recs.begin(), bu.recs.end());
     }
-    if (mrec.size() / 3 >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
-    cell_start.push_back((uint32_t)(mrec.size() / 3)); /* end of the last cell */
-    if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)(mrec.size() / 3);
-    if (mrec.empty()) mrec.resize(3, make_float4(0, 0, 0, 0));
+    if (mrec.size() >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
+    cell_start.push_back((uint32_t)mrec.size()); /* end of the last cell */
+    if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)mrec.size();
   }
+  float qs;
+  {
+    const double *b3[3] = {xs, ys, zs};
+    qs = record_quantum(b3, n_sv);
+  }
+  std::vector<uint4> packed;
+  pack_records(mrec, qs, packed);
   if (host_only) { /* no device involved */
     host_only->lk = lk;
     host_only->sv_base.swap(sv_base);
     host_only->cell_start.swap(cell_start);
-    host_only->mrec.swap(mrec);
+    host_only->recs.swap(mrec);
+    host_only->mrec.swap(packed);
+    host_only->qs = qs;
     return DSIM_OK;
   }
   std::vector<double> bounds;
@@ -623,10 +668,11 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
   HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&dm.mrec, mrec.size() * sizeof(float4)));
+  HIP_TRY(hipMalloc(&dm.mrec, packed.size() * sizeof(uint4)));
   HIP_TRY(hipMalloc(&dm.sv_base, sv_base.size() * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&dm.cell_start, cell_start.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpyAsync(dm.mrec, mrec.data(), mrec.size() * sizeof(float4), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.mrec, packed.data(), packed.size() * sizeof(uint4), hipMemcpyHostToDevice, stream));
+  dm.qs = qs;
   HIP_TRY(hipMemcpyAsync(dm.sv_base, sv_base.data(), sv_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(dm.cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   dm.lk = lk;
@@ -686,6 +732,7 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
   m.mrec = dm.mrec;
+  m.qs = dm.qs;
   m.sv_base = dm.sv_base;
   m.cell_start = dm.cell_start;
   m.cell_dense = dm.cell_dense;

@@ -235,14 +235,17 @@ int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertices, const in
  * (sv_base[s] = -1: empty), slot ((i * 2k + j) * k + c) = the cell that starts at unit i along x, unit j along y, z cell c
  * (the slots with i or j = 2k - 1 stay empty).  The records of slot q are [cell_start[q], cell_start[q + 1]).  Per record
  * the triangle, its position in the reference's triangle_indices and the float32 box {min x, y, z, max x, y, z} of the
- * triangle's part inside the cell.  Exported so that the completeness of the grid can be tested without a GPU
+ * triangle's part inside the cell; rec_packed (8 dwords per record, may be NULL): the 32-byte record as the kernels read
+ * it - {lo_x | lo_y << 16, lo_z | nhi_x << 16, nhi_y | nhi_z << 16, triangle, plane nx, ny, nz, c as float32 bits}, the box
+ * in 15-bit fixed point x -> x * *quantum (one float, may be NULL), lo rounded down, hi rounded up and stored as
+ * nhi = 32767 - hi.  Exported so that the completeness of the grid can be tested without a GPU
  * (tests/test_fine_grid.py).  Call once with cell_start == NULL for the sizes, then with buffers of *n_cells + 1 and
  * *n_records elements. */
 int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
                         const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
                         const int64_t *triangle_indices, int64_t n_refs, double step_l, int32_t *log2_cells, int64_t *n_cells,
                         int64_t *n_records, int32_t *sv_base, uint32_t *cell_start, int32_t *rec_triangle, int32_t *rec_position,
-                        float *rec_box);
+                        float *rec_box, uint32_t *rec_packed, float *quantum);
 
 /* The two predicates dsim_mesh_subdivide is built from, exported for unit tests
  * that mirror disimpy/tests/test_substrates.py:293-345: triangle (3,3) vs box

@@ -106,3 +106,30 @@ def test_fine_grid_is_complete(lib, name, sub, step_l):
         n_rec = np.diff(cs).reshape(-1, ku, ku, k)
         assert n_rec[:, ku - 1].sum() == 0 and n_rec[:, :, ku - 1].sum() == 0
     assert checked > 1000 and inside > 100
+
+
+@pytest.mark.parametrize("name,sub,step_l", list(_substrates()), ids=lambda v: v if isinstance(v, str) else "")
+def test_packed_records_hold_their_float32_boxes(lib, name, sub, step_l):
+    """The 32-byte records the kernels read (MeshDev::mrec, dsim_kernels.h): the fixed-point box is the float32 box
+    rounded OUTWARDS (never tighter, at most two quanta wider), so whatever overlapped the float32 box overlaps it."""
+    fg = lib.mesh_fine_grid(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices, step_l)
+    pk, box, qs = fg["packed"], fg["box"].astype(np.float64), np.float64(np.float32(fg["quantum"]))
+    assert qs > 0 and abs(qs * max(sub.xs[-1], sub.ys[-1], sub.zs[-1]) - 32767.0) < 0.01
+    lo = np.stack([pk[:, 0] & 0xFFFF, pk[:, 0] >> 16, pk[:, 1] & 0xFFFF], axis=1).astype(np.float64)
+    nhi = np.stack([pk[:, 1] >> 16, pk[:, 2] & 0xFFFF, pk[:, 2] >> 16], axis=1).astype(np.float64)
+    hi = 32767.0 - nhi
+    assert lo.max() <= 32767 and nhi.max() <= 32767
+    v_lo, v_hi = box[:, :3] * qs, box[:, 3:] * qs
+    inside = (v_lo >= 0) & (v_hi <= 32767)
+    assert np.all(lo <= np.maximum(v_lo, 0)) and np.all(hi >= np.minimum(v_hi, 32767))
+    assert np.all((v_lo - lo)[inside] < 1.001) and np.all((hi - v_hi)[inside] < 1.001)
+    np.testing.assert_array_equal(pk[:, 3].astype(np.int64), fg["tri"].astype(np.int64))
+    # the plane: unit normal and offset of the record's triangle in float32
+    V, F = np.asarray(sub.vertices), np.asarray(sub.faces)
+    t = fg["tri"][:: max(1, len(pk) // 2000)]
+    n = pk[:: max(1, len(pk) // 2000), 4:7].copy().view(np.float32).astype(np.float64)
+    c = pk[:: max(1, len(pk) // 2000), 7].copy().view(np.float32).astype(np.float64)
+    a, b, cc = V[F[t, 0]], V[F[t, 1]], V[F[t, 2]]
+    want = np.cross(b - a, cc - a)
+    want /= np.linalg.norm(want, axis=1)[:, None]
+    assert np.abs(n - want).max() < 1e-6 and np.abs(np.einsum("ij,ij->i", n, a) - c).max() < 1e-6 * np.abs(V).max()
