@@ -63,6 +63,17 @@
 #define COOP_PRIO_ARITHMETIC() __builtin_amdgcn_s_setprio(0)
 
 #define COOP_ITEM_CAP 320
+/* records per item (stage 2 tests them in one trip).  [r5] 5 of the 32-byte records (40 VGPRs; four 48-byte records took
+ * 44): a pass of the refined neuron then needs 1.92 items per walker instead of 2.31 (the mean run holds 8 records) and
+ * its items are two trips of stage 2 more often than three.  Same-box A/B (profiles/history/r05_ab_item_size.txt): C5b
+ * +3.7 % at 1e7 and at 1.25e6 walkers, C4 +0.4 %; 6 records per item need 5 spilled VGPRs at four wavefronts per SIMD and
+ * lose what they gain (0 / -1 % / -4.6 %).  -DDSIM_ITEM_RECS=4 / 6 / 8 for comparison (at most 8: three bits of an item
+ * hold the count) */
+#ifndef DSIM_ITEM_RECS
+#define DSIM_ITEM_RECS 5
+#endif
+#define COOP_ITEM_RECS DSIM_ITEM_RECS
+#define COOP_ITEM_FIRST_MASK 0x1fffffffu /* 29 bits of first record, 3 bits of count - 1 */
 #define COOP_SURV_CAP 128
 #define COOP_RUNQ_CAP 320 /* slots 0..63: the first run of owner 0..63; the other runs behind */
 #define COOP_MAX_RUNS 64  /* per owner and pass */
@@ -78,7 +89,7 @@ struct CoopWave {
   unsigned more[COOP_RUNQ_CAP - 64]; /* the other runs, by name only: owner | number of the run << 6              1.5 KB */
   int4 plan_a[64];                 /* what the runs of an owner are numbered over (RunPlan): a0, b0, c0, c1 ...          */
   int2 plan_b[64];                 /*   ... first z unit, columns in y | z units << 8 | n0a << 16 | n0b << 24      1.5 KB */
-  uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 30, owner | shifts << 6} (1c -> 2)  2.5 KB */
+  uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 29, owner | shifts << 6} (1c -> 2)  2.5 KB */
   unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
   unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6                                                   1.0 KB */
   unsigned char overflow[64];      /* some work of this owner did not fit a queue: redo serially                     */
@@ -532,9 +543,15 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     /* the records of a run as items of four; the last one holds what is left (its count goes in after the loop: the loop
      * itself is one store and two additions per item - its trip count is the longest run of the 64) */
     auto write_items = [&](uint2 *q, int first, int cnt, int nb, unsigned tag) {
-      unsigned x = (unsigned)first | (3u << 30);
-      for (uint2 *const end = q + nb - 1; q < end; q++, x += 4u) *q = make_uint2(x, tag);
-      *q = make_uint2((x & 0x3fffffffu) | ((unsigned)(cnt - 4 * (nb - 1) - 1) << 30), tag);
+      unsigned x = (unsigned)first | ((unsigned)(COOP_ITEM_RECS - 1) << 29);
+      for (uint2 *const end = q + nb - 1; q < end; q++, x += (unsigned)COOP_ITEM_RECS) *q = make_uint2(x, tag);
+      *q = make_uint2((x & COOP_ITEM_FIRST_MASK) | ((unsigned)(cnt - COOP_ITEM_RECS * (nb - 1) - 1) << 29), tag);
+    };
+    /* items of a run of n records (n <= 1024: longer runs go to their owner's serial pass - COOP_ITEM_CAP) */
+    auto n_items_of = [](int n) -> int {
+      if (COOP_ITEM_RECS == 4) return (n + 3) >> 2;
+      if (COOP_ITEM_RECS == 8) return (n + 7) >> 3;
+      return (int)(((unsigned)(n + COOP_ITEM_RECS - 1) * (unsigned)(65536 / COOP_ITEM_RECS + 1)) >> 16); /* exact below 2^14 */
     };
     while (cur_a < 64 || cur_b < n_extra) {
       /* -- 1c: up to 64 first runs and 64 extra runs per trip, one of each per lane */
@@ -555,7 +572,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         const int2 ra = look_up(ea);
         int2 rb = make_int2(0, 0);
         if (extras) rb = look_up(eb);
-        const int nba = (ra.y + 3) >> 2, nbb = (rb.y + 3) >> 2, nb = nba + nbb;
+        const int nba = n_items_of(min(ra.y, 8192)), nbb = n_items_of(min(rb.y, 8192)), nb = nba + nbb;
         if (nb > 0) {
           STAT_LANE(3);
           STAT_WAVE(3);
@@ -602,11 +619,11 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         if (valid) it = W->items[idx];
         /* the records first: their addresses only need the item, so the 8 loads are in flight while the owner's
          * segment comes through the shuffles (a lane without an item reads record 0) */
-        const int first_rec = valid ? (int)(it.x & 0x3fffffffu) : 0, cnt = valid ? (int)(it.x >> 30) + 1 : 1;
-        ds_uint4 q0[4], q1[4];
+        const int first_rec = valid ? (int)(it.x & COOP_ITEM_FIRST_MASK) : 0, cnt = valid ? (int)(it.x >> 29) + 1 : 1;
+        ds_uint4 q0[COOP_ITEM_RECS], q1[COOP_ITEM_RECS];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads records 0..3 */
+        for (int u = 0; u < COOP_ITEM_RECS; u++) {
+          const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads the first records of the index */
           q0[u] = ms.mrec[2 * j];
           q1[u] = ms.mrec[2 * j + 1];
         }
@@ -638,32 +655,37 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
          * the item's count repeat its last record (loads stay unconditional) and do not count.  The results never become
          * a per-lane word: a comparison IS the wave's ballot of it */
         const bool on = valid && !ABLATE(3) && !ABLATE(4);
-        const bool s0 = record_survives(q0[0], q1[0], b0, b1, b2, mh_x, mh_y, mh_z, tau), s1 = record_survives(q0[1], q1[1], b0, b1, b2, mh_x, mh_y, mh_z, tau);
-        const bool s2 = record_survives(q0[2], q1[2], b0, b1, b2, mh_x, mh_y, mh_z, tau), s3 = record_survives(q0[3], q1[3], b0, b1, b2, mh_x, mh_y, mh_z, tau);
-        const bool a0 = on & s0, a1 = on & (cnt > 1) & s1, a2 = on & (cnt > 2) & s2, a3 = on & (cnt > 3) & s3; /* & not &&: no branches */
-        { /* the survivors' slots from four ballots (survivors in lower lanes first): the pool's fill level stays in a
-           * scalar register, there is no LDS atomic to wait for and no counter to read back before the flush check
-           * (round 2 / early round 3: one LDS atomic per lane and an LDS read per trip; C5b +1.4 %, C4 +1.7 %) */
-          const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1), m2 = __ballot(a2), m3 = __ballot(a3);
-          if ((m0 | m1 | m2 | m3) != 0ULL) {
-            unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
-            below = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, below));
-            below = __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, below));
-            below = __builtin_amdgcn_mbcnt_hi((unsigned)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m3, below));
-            int slot = n_surv + (int)below;
-            const bool alive[4] = {a0, a1, a2, a3};
+        bool alive[COOP_ITEM_RECS];
+        unsigned long long mask[COOP_ITEM_RECS], any = 0ULL;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              if (!alive[u]) continue;
-              if (slot < COOP_SURV_CAP) {
-                W->surv_tri[slot] = q0[u].w;
-                W->surv_tag[slot] = it.y;
-              } else
-                W->overflow[owner] = 1;
-              slot++;
-            }
-            n_surv = min(n_surv + (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)), COOP_SURV_CAP);
+        for (int u = 0; u < COOP_ITEM_RECS; u++) {
+          alive[u] = on & (cnt > u) & record_survives(q0[u], q1[u], b0, b1, b2, mh_x, mh_y, mh_z, tau); /* & not &&: no branches */
+          mask[u] = __ballot(alive[u]);
+          any |= mask[u];
+        }
+        /* the survivors' slots from the ballots (survivors in lower lanes first): the pool's fill level stays in a
+         * scalar register, there is no LDS atomic to wait for and no counter to read back before the flush check
+         * (round 2 / early round 3: one LDS atomic per lane and an LDS read per trip; C5b +1.4 %, C4 +1.7 %) */
+        if (any != 0ULL) {
+          unsigned below = 0u;
+          int total = 0;
+#pragma unroll
+          for (int u = 0; u < COOP_ITEM_RECS; u++) {
+            below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], below));
+            total += (int)__popcll(mask[u]);
           }
+          int slot = n_surv + (int)below;
+#pragma unroll
+          for (int u = 0; u < COOP_ITEM_RECS; u++) {
+            if (!alive[u]) continue;
+            if (slot < COOP_SURV_CAP) {
+              W->surv_tri[slot] = q0[u].w;
+              W->surv_tag[slot] = it.y;
+            } else
+              W->overflow[owner] = 1;
+            slot++;
+          }
+          n_surv = min(n_surv + total, COOP_SURV_CAP);
         }
         T_MARK(W, lane, 4);
         wave_sync();

@@ -628,7 +628,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       mrec.insert(mrec.end(), bu.recs.begin(), bu.recs.end());
     }
-    if (mrec.size() >= 0x40000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records");
+    if (mrec.size() >= 0x20000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* an item of the cooperative traversal names a record in 29 bits */
     cell_start.push_back((uint32_t)mrec.size()); /* end of the last cell */
     if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)mrec.size();
   }

@@ -29,6 +29,11 @@ PASSES = {
     # SQ_LDS_BANK_CONFLICT = extra cycles, SQ_LDS_IDX_ACTIVE = all LDS-array cycles)
     "lds": "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INSTS_LDS "
            "SQ_WAVE_CYCLES",
+    # instruction mix of the vector ALU: which share of the instructions are fp64 / 64-bit integer (quarter-rate class)
+    "mix": "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 "
+           "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT",
+    "mix2": "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU "
+            "SQ_INSTS_SMEM SQ_INSTS_LDS",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
 }
@@ -61,7 +66,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
     ap.add_argument("--walkers", type=int, default=1_000_000)
-    ap.add_argument("--tag", default="r04")
+    ap.add_argument("--tag", default="r05")
     ap.add_argument("--match", default="walk_kernel")
     ap.add_argument("--passes", default="sq,mem,fetch,write")
     ap.add_argument("--bench-args", default="")
@@ -116,6 +121,16 @@ def main():
         entry["l2_read_req_per_wave_step"] = m["TCP_TCC_READ_REQ_sum"] / ws
         if "sq" in raw:  # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
             entry["valu_busy"] = raw["sq"]["counters"]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (m["GRBM_GUI_ACTIVE"] / 8)
+    if "mix" in raw:
+        c = raw["mix"]["counters"]
+        entry["valu_mix_per_wave_step"] = {k.replace("SQ_INSTS_VALU_", "").lower(): v / ws for k, v in c.items() if k != "SQ_INSTS_VALU"}
+        entry["valu_mix_per_wave_step"]["all"] = c.get("SQ_INSTS_VALU", 0.0) / ws
+    if "mix2" in raw:
+        c = raw["mix2"]["counters"]
+        entry.setdefault("valu_mix_per_wave_step", {}).update(
+            {k.replace("SQ_INSTS_VALU_", "").replace("SQ_INSTS_", "").lower(): v / ws for k, v in c.items() if k.startswith("SQ_INSTS")})
+        if c.get("SQ_ACTIVE_INST_VALU"):  # lanes active per vector instruction (64 = no divergence)
+            entry["valu_lanes_active_mean"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_ACTIVE_INST_VALU"]
     if "lds" in raw:
         c = raw["lds"]["counters"]
         if c.get("SQ_LDS_IDX_ACTIVE"):
