@@ -65,7 +65,7 @@
 #define COOP_ITEM_CAP 320
 /* records per item (stage 2 tests them in one trip).  [r5] 5 of the 32-byte records (40 VGPRs; four 48-byte records took
  * 44): a pass of the refined neuron then needs 1.92 items per walker instead of 2.31 (the mean run holds 8 records) and
- * its items are two trips of stage 2 more often than three.  Same-box A/B (profiles/history/r05_ab_item_size.txt): C5b
+ * its items are two trips of stage 2 more often than three.  Same-box A/B (profiles/history/r05_ab_mesh_kernel_steps.txt): C5b
  * +3.7 % at 1e7 and at 1.25e6 walkers, C4 +0.4 %; 6 records per item need 5 spilled VGPRs at four wavefronts per SIMD and
  * lose what they gain (0 / -1 % / -4.6 %).  -DDSIM_ITEM_RECS=4 / 6 / 8 for comparison (at most 8: three bits of an item
  * hold the count) */
