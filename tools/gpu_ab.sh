@@ -6,7 +6,7 @@ TAG=$1; WL=$2; N=$3; LIBS=$4; EXTRA=$5
 mkdir -p gpurun_out/${ROUND:-r04}
 for rep in $(seq 1 ${REPS:-2}); do for lib in $LIBS; do
   name=$(basename $lib .so)
-  out=gpurun_out/${ROUND:-r04}/ab_${TAG}_${name}_${rep}
+  out=gpurun_out/${ROUND:-r04}/ab_${TAG}_${WL}_${N}_${name}_${rep}
   DSIM_BENCH_POSITIONS_CACHE=/tmp/pos_${WL}_${N}.npy DSIM_LIB_OLD_ABI=1 DSIM_LIB=$PWD/disimpy_amd/csrc/$lib timeout -k 5 400 python bench.py --workload $WL --walkers $N --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check $EXTRA > $out.json 2> $out.err
   python - <<PY
 import json
