@@ -20,7 +20,8 @@ SYMBOLS = (
     "dsim_fill_mesh", "dsim_mesh_subdivide", "dsim_mesh_clearance_map", "dsim_triangle_box_overlap", "dsim_interval_sv_overlap",
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
     "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close", "dsim_mesh_fine_grid",
-    "dsim_create_multi", "dsim_shard_count", "dsim_get_signal_limbs", "dsim_signal_from_limbs",
+    "dsim_create_multi", "dsim_shard_count", "dsim_get_signal_limbs", "dsim_signal_from_limbs", "dsim_partition_by_position",
+    "dsim_partition_walkers", "dsim_set_walker_ids",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -70,6 +71,9 @@ def load():
     lib.dsim_shard_count.argtypes = [_h]
     lib.dsim_destroy.argtypes = [_h]
     lib.dsim_set_positions.argtypes = [_h, _f64p]
+    lib.dsim_partition_by_position.argtypes = [_h, _f64p]
+    lib.dsim_partition_walkers.argtypes = [_f64p, C.c_int64, C.c_int32, _i64p, _i64p]
+    lib.dsim_set_walker_ids.argtypes = [_h, _i64p]
     lib.dsim_set_rng_states.argtypes = [_h, _u64p]
     lib.dsim_set_mesh.argtypes = [_h, _f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p,
                                   C.c_int64]
@@ -207,6 +211,16 @@ def mesh_fine_grid(vertices, faces, xs, ys, zs, n_sv, subvoxel_indices, triangle
                 box=box[: nr.value], packed=packed[: nr.value], quantum=float(quantum[0]))
 
 
+def partition_walkers(positions, n_parts):
+    """The walkers cut into n_parts by space (include/dsim.h, dsim_partition_walkers; host only).  Returns the list of
+    the parts' walker indices (each ascending) - balanced sizes, Morton order of the positions."""
+    pos = _c(positions, np.float64)
+    n = len(pos)
+    ids, start = np.zeros(max(n, 1), dtype=np.int64), np.zeros(n_parts + 1, dtype=np.int64)
+    check(load().dsim_partition_walkers(p_f64(pos), n, int(n_parts), p_i64(ids), p_i64(start)))
+    return [ids[start[k]: start[k + 1]].copy() for k in range(n_parts)]
+
+
 def triangle_box_overlap(triangle, box):
     t, b = _c(triangle, np.float64), _c(box, np.float64)
     rc = load().dsim_triangle_box_overlap(p_f64(t), p_f64(b))
@@ -271,6 +285,21 @@ class Sim:
         pos = _c(pos, np.float64)
         assert pos.shape == (self.n, 3)
         check(self._lib.dsim_set_positions(self._h, p_f64(pos)))
+
+    def partition_by_position(self, pos):
+        """set_positions that also cuts a multi-device handle's walkers into its shards by space (include/dsim.h)"""
+        pos = _c(pos, np.float64)
+        assert pos.shape == (self.n, 3)
+        check(self._lib.dsim_partition_by_position(self._h, p_f64(pos)))
+
+    def set_walker_ids(self, ids):
+        """single-device handle: slot i holds walker first_walker + ids[i] (ascending); None: the range again"""
+        if ids is None:
+            check(self._lib.dsim_set_walker_ids(self._h, None))
+            return
+        ids = _c(ids, np.int64)
+        assert ids.shape == (self.n,)
+        check(self._lib.dsim_set_walker_ids(self._h, p_i64(ids)))
 
     def set_rng_states(self, states):
         st = _c(states, np.uint64)

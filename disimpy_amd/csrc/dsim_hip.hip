@@ -149,11 +149,11 @@ extern "C" int dsim_rng_init(uint64_t seed, uint64_t first_index, uint64_t n, ui
 }
 
 /* device-side parallel seeding */
-__global__ void rng_init_kernel(uint64_t seed_s0, uint64_t seed_s1, uint64_t first, int64_t n, const uint64_t *cols,
+__global__ void rng_init_kernel(uint64_t seed_s0, uint64_t seed_s1, uint64_t first, const int64_t *ids, int64_t n, const uint64_t *cols,
                                 int levels, uint64_t *s0, uint64_t *s1) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint64_t idx = first + (uint64_t)i;
+  uint64_t idx = first + (uint64_t)(ids != nullptr ? ids[i] : i); /* slot i holds walker first + ids[i] (a shard cut by space) */
   uint64_t a = seed_s0, c = seed_s1;
   for (int k = 0; k < levels && (idx >> k); k++) {
     if (!(idx >> k & 1)) continue;
@@ -251,6 +251,14 @@ struct dsim_sim {
    * each on a host thread of its own */
   std::vector<dsim_sim *> shards;
   std::vector<int64_t> shard_off;
+  /* [r5] shards cut by SPACE (dsim_partition_by_position): shard k holds the walkers shard_ids[k] (indices inside the
+   * handle, ascending), not the range that starts at shard_off[k]; empty: the contiguous ranges.  Host arrays of the
+   * handle stay in walker order - rows are gathered / scattered through the lists */
+  std::vector<std::vector<int64_t>> shard_ids;
+  /* a shard of such a handle: the walker of slot i is first + walker_ids[i] (device array; the RNG seeding needs it) */
+  int64_t *walker_ids = nullptr;
+  bool seeded = false, states_given = false, has_run = false; /* what a re-partition would have to redo */
+  uint64_t seed_value = 0;
 };
 
 /* f(k, shard, first walker of the shard inside the handle) for every shard of a multi-device handle, concurrently (one
@@ -286,6 +294,27 @@ static int multi_each(dsim_sim *h, F f) {
         return (__VA_ARGS__);                                                         \
       });                                                                             \
   } while (0)
+
+/* rows of a per-walker array: the shard's (n_k, row) block out of / into the handle's (n, row) array in walker order */
+static const void *shard_rows_in(const dsim_sim *h, int k, int64_t off, const void *whole, size_t row, std::vector<char> &tmp) {
+  if (h->shard_ids.empty()) return (const char *)whole + (size_t)off * row;
+  const std::vector<int64_t> &ids = h->shard_ids[(size_t)k];
+  tmp.resize(ids.size() * row);
+  for (size_t j = 0; j < ids.size(); j++) memcpy(tmp.data() + j * row, (const char *)whole + (size_t)ids[j] * row, row);
+  return tmp.data();
+}
+static void shard_rows_out(const dsim_sim *h, int k, int64_t off, void *whole, size_t row, const void *part, int64_t n_k) {
+  if (h->shard_ids.empty()) {
+    memcpy((char *)whole + (size_t)off * row, part, (size_t)n_k * row);
+    return;
+  }
+  const std::vector<int64_t> &ids = h->shard_ids[(size_t)k];
+  if (row == 8) {
+    for (size_t j = 0; j < ids.size(); j++) ((uint64_t *)whole)[ids[j]] = ((const uint64_t *)part)[j];
+    return;
+  }
+  for (size_t j = 0; j < ids.size(); j++) memcpy((char *)whole + (size_t)ids[j] * row, (const char *)part + j * row, row);
+}
 
 static int ensure_staging(dsim_sim *h, size_t bytes) {
   if (h->staging_bytes >= bytes) return DSIM_OK;
@@ -337,6 +366,7 @@ extern "C" int dsim_destroy(dsim_handle h) {
     if (h->sort_offs[g]) (void)hipFree(h->sort_offs[g]);
   }
   if (h->bin_of) (void)hipFree(h->bin_of);
+  if (h->walker_ids) (void)hipFree(h->walker_ids);
   free_mesh(h->mesh);
   for (hipEvent_t e : h->walk_ev) (void)hipEventDestroy(e);
   for (int b = 0; b < 2; b++) {
@@ -484,7 +514,13 @@ extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_s
 static inline int grid_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
-  MULTI_FORWARD(h, pos ? dsim_set_positions(s_, pos + 3 * off_) : fail(DSIM_ERR_INVALID, "dsim_set_positions: null argument"));
+  if (IS_MULTI(h)) {
+    if (!pos) return fail(DSIM_ERR_INVALID, "dsim_set_positions: null argument");
+    return multi_each(h, [&](int k, dsim_sim *sh, int64_t off) -> int {
+      std::vector<char> tmp;
+      return dsim_set_positions(sh, (const double *)shard_rows_in(h, k, off, pos, 24, tmp));
+    });
+  }
   if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_set_positions: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 3 * sizeof(double));
@@ -496,8 +532,155 @@ extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
   return DSIM_OK;
 }
 
+/* [r5] Walkers cut into n_shards parts by SPACE: the walkers are ordered along the Morton curve of `pos` (21 bits per
+ * axis, cubic cells over the bounding box of the finite coordinates; ties by walker index) and part k is the k-th stretch of that
+ * order, of the balanced sizes of the contiguous cut (the first n % n_shards parts hold one walker more).  ids_out
+ * (n): the walkers of part 0 in ascending order, then those of part 1, ...; part_start (n_shards + 1): where each part
+ * begins in ids_out.  Host only, deterministic - every rank of a job computes the same cut from the same positions. */
+extern "C" int dsim_partition_walkers(const double *pos, int64_t n, int32_t n_shards, int64_t *ids_out, int64_t *part_start) {
+  if (!pos || !ids_out || !part_start || n < 0 || n_shards < 1) return fail(DSIM_ERR_INVALID, "dsim_partition_walkers: bad argument");
+  const size_t G = (size_t)n_shards;
+  const int64_t base = n / n_shards, extra = n % n_shards;
+  for (size_t k = 0; k <= G; k++) part_start[k] = (int64_t)k * base + std::min<int64_t>((int64_t)k, extra);
+  if (n == 0) return DSIM_OK;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t i = 0; i < n; i++)
+    for (int c = 0; c < 3; c++) {
+      const double v = pos[3 * i + c];
+      if (std::isfinite(v)) lo[c] = std::min(lo[c], v), hi[c] = std::max(hi[c], v);
+    }
+  /* ONE scale for the three axes: the cells of the curve are cubes in space (a thin substrate keeps its thin axis' top bits at 0) */
+  double ext = 0;
+  for (int c = 0; c < 3; c++) ext = std::max(ext, hi[c] - lo[c]);
+  const double scale[3] = {ext > 0 ? 2097151.0 / ext : 0.0, ext > 0 ? 2097151.0 / ext : 0.0, ext > 0 ? 2097151.0 / ext : 0.0};
+  auto spread = [](uint64_t v) { /* 21 bits -> every third bit */
+    v &= 0x1fffffULL;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+  };
+  struct Key {
+    uint64_t key;
+    int64_t idx;
+    bool operator<(const Key &o) const { return key != o.key ? key < o.key : idx < o.idx; }
+  };
+  std::vector<Key> keys((size_t)n);
+  {
+    const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n / 65536));
+    auto work = [&](int64_t a, int64_t b) {
+      for (int64_t i = a; i < b; i++) {
+        uint64_t q[3];
+        for (int c = 0; c < 3; c++) {
+          const double v = pos[3 * i + c];
+          const double t = std::isfinite(v) ? (v - lo[c]) * scale[c] : 0.0;
+          q[c] = (uint64_t)std::min(2097151.0, std::max(0.0, t));
+        }
+        keys[(size_t)i] = Key{spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]), i};
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work, n * (int64_t)t / n_thr, n * (int64_t)(t + 1) / n_thr);
+    work(0, n / n_thr);
+    for (auto &t : th) t.join();
+  }
+  /* only the cut points matter, not the order inside a part: bisect with nth_element, O(n log G) */
+  std::function<void(size_t, size_t)> cut = [&](size_t a, size_t b) { /* parts [a, b) own keys[part_start[a], part_start[b]) */
+    if (b - a < 2) return;
+    const size_t m = (a + b) / 2;
+    std::nth_element(keys.begin() + part_start[a], keys.begin() + part_start[m], keys.begin() + part_start[b]);
+    std::thread left(cut, a, m);
+    cut(m, b);
+    left.join();
+  };
+  cut(0, G);
+  std::vector<std::thread> th;
+  auto finish = [&](size_t k) {
+    int64_t *ids = ids_out + part_start[k];
+    const int64_t cnt = part_start[k + 1] - part_start[k];
+    for (int64_t j = 0; j < cnt; j++) ids[j] = keys[(size_t)(part_start[k] + j)].idx;
+    std::sort(ids, ids + cnt); /* walker order inside the part */
+  };
+  for (size_t k = 1; k < G; k++) th.emplace_back(finish, k);
+  finish(0);
+  for (auto &t : th) t.join();
+  return DSIM_OK;
+}
+
+/* Single-device handle: slot i holds walker first_walker + ids[i] instead of first_walker + i (ids ascending, n of
+ * them; NULL: back to the range).  Only the RNG seeding looks at it (dsim_rng_init_device: walker i <- state i) - a
+ * process that owns a part of dsim_partition_walkers sets it before seeding.  Not for multi-device handles, which keep
+ * their own lists (dsim_partition_by_position). */
+extern "C" int dsim_set_walker_ids(dsim_handle h, const int64_t *ids) {
+  if (!h || IS_MULTI(h)) return fail(DSIM_ERR_INVALID, "dsim_set_walker_ids: needs a single-device handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (!ids) {
+    if (h->walker_ids) (void)hipFree(h->walker_ids);
+    h->walker_ids = nullptr;
+    return DSIM_OK;
+  }
+  for (int64_t i = 0; i < h->n; i++)
+    if (ids[i] < 0 || (i > 0 && ids[i] <= ids[i - 1])) return fail(DSIM_ERR_INVALID, "dsim_set_walker_ids: ids must be ascending and >= 0");
+  if (!h->walker_ids) HIP_TRY(hipMalloc(&h->walker_ids, (size_t)h->n * sizeof(int64_t)));
+  HIP_TRY(hipMemcpy(h->walker_ids, ids, (size_t)h->n * sizeof(int64_t), hipMemcpyHostToDevice));
+  return DSIM_OK;
+}
+
+/* [r5] Cut the walkers of a multi-device handle into its shards by SPACE (dsim_partition_walkers) and set their
+ * positions.  A mesh shard then works in ITS part of the substrate: at an eighth of the walkers per region a GPU of an
+ * 8-GPU job dragged the whole index through its caches (the fill emits positions in (launch, thread) order: a range of
+ * indices is a random sample of every dendrite).  Nothing else changes: walker i keeps RNG state i (rng_init_kernel
+ * takes the index list) and position i, every host array of the handle stays in walker order (rows are gathered /
+ * scattered through the lists), the exact integer signal sums do not depend on the cut.  Call it instead of
+ * dsim_set_positions, before the first run; RNG states seeded with dsim_rng_init_device are re-seeded under the new cut,
+ * states given with dsim_set_rng_states are moved.  On a single-device handle: dsim_set_positions. */
+extern "C" int dsim_partition_by_position(dsim_handle h, const double *pos) {
+  if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_partition_by_position: null argument");
+  if (!IS_MULTI(h) || h->shards.size() < 2) return dsim_set_positions(h, pos);
+  if (h->has_run) return fail(DSIM_ERR_STATE, "dsim_partition_by_position: the handle has already run");
+  const int64_t n = h->n;
+  const size_t G = h->shards.size();
+  std::vector<uint64_t> states;
+  if (h->states_given) { /* explicit RNG states: collect them under the old cut */
+    states.resize((size_t)n * 2);
+    const int rc = dsim_get_rng_states(h, states.data());
+    if (rc) return rc;
+  }
+  /* the shards were created with the balanced contiguous sizes - exactly the parts of dsim_partition_walkers when no
+   * shard is empty (more devices than walkers leaves shards out: then the sizes differ and the range cut stays) */
+  if ((int64_t)G > n) return dsim_set_positions(h, pos);
+  std::vector<int64_t> ids((size_t)n), start(G + 1);
+  int rc = dsim_partition_walkers(pos, n, (int32_t)G, ids.data(), start.data());
+  if (rc) return rc;
+  for (size_t k = 0; k < G; k++)
+    if (start[k + 1] - start[k] != h->shards[k]->n) return fail(DSIM_ERR_STATE, "dsim_partition_by_position: shard sizes do not match");
+  h->shard_ids.assign(G, std::vector<int64_t>());
+  rc = multi_each(h, [&](int k, dsim_sim *sh, int64_t) -> int {
+    h->shard_ids[(size_t)k].assign(ids.begin() + start[(size_t)k], ids.begin() + start[(size_t)k + 1]);
+    sh->first = h->first; /* slot i holds walker first + ids[i] */
+    return dsim_set_walker_ids(sh, h->shard_ids[(size_t)k].data());
+  });
+  if (rc) return rc;
+  rc = dsim_set_positions(h, pos);
+  if (rc) return rc;
+  if (h->seeded) return dsim_rng_init_device(h, h->seed_value);
+  if (h->states_given) return dsim_set_rng_states(h, states.data());
+  return DSIM_OK;
+}
+
 extern "C" int dsim_get_positions(dsim_handle h, double *pos) {
-  MULTI_FORWARD(h, pos ? dsim_get_positions(s_, pos + 3 * off_) : fail(DSIM_ERR_INVALID, "dsim_get_positions: null argument"));
+  if (IS_MULTI(h)) {
+    if (!pos) return fail(DSIM_ERR_INVALID, "dsim_get_positions: null argument");
+    return multi_each(h, [&](int k, dsim_sim *sh, int64_t off) -> int {
+      if (h->shard_ids.empty()) return dsim_get_positions(sh, pos + 3 * off);
+      std::vector<double> part((size_t)sh->n * 3);
+      const int rc = dsim_get_positions(sh, part.data());
+      if (rc == DSIM_OK) shard_rows_out(h, k, off, pos, 24, part.data(), sh->n);
+      return rc;
+    });
+  }
   if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_get_positions: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 3 * sizeof(double));
@@ -510,7 +693,14 @@ extern "C" int dsim_get_positions(dsim_handle h, double *pos) {
 }
 
 extern "C" int dsim_set_rng_states(dsim_handle h, const uint64_t *st) {
-  MULTI_FORWARD(h, st ? dsim_set_rng_states(s_, st + 2 * off_) : fail(DSIM_ERR_INVALID, "dsim_set_rng_states: null argument"));
+  if (IS_MULTI(h)) {
+    if (!st) return fail(DSIM_ERR_INVALID, "dsim_set_rng_states: null argument");
+    h->states_given = true, h->seeded = false;
+    return multi_each(h, [&](int k, dsim_sim *sh, int64_t off) -> int {
+      std::vector<char> tmp;
+      return dsim_set_rng_states(sh, (const uint64_t *)shard_rows_in(h, k, off, st, 16, tmp));
+    });
+  }
   if (!h || !st) return fail(DSIM_ERR_INVALID, "dsim_set_rng_states: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 2 * sizeof(uint64_t));
@@ -523,7 +713,16 @@ extern "C" int dsim_set_rng_states(dsim_handle h, const uint64_t *st) {
 }
 
 extern "C" int dsim_get_rng_states(dsim_handle h, uint64_t *st) {
-  MULTI_FORWARD(h, st ? dsim_get_rng_states(s_, st + 2 * off_) : fail(DSIM_ERR_INVALID, "dsim_get_rng_states: null argument"));
+  if (IS_MULTI(h)) {
+    if (!st) return fail(DSIM_ERR_INVALID, "dsim_get_rng_states: null argument");
+    return multi_each(h, [&](int k, dsim_sim *sh, int64_t off) -> int {
+      if (h->shard_ids.empty()) return dsim_get_rng_states(sh, st + 2 * off);
+      std::vector<uint64_t> part((size_t)sh->n * 2);
+      const int rc = dsim_get_rng_states(sh, part.data());
+      if (rc == DSIM_OK) shard_rows_out(h, k, off, st, 16, part.data(), sh->n);
+      return rc;
+    });
+  }
   if (!h || !st) return fail(DSIM_ERR_INVALID, "dsim_get_rng_states: null argument");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_staging(h, (size_t)h->n * 2 * sizeof(uint64_t));
@@ -536,6 +735,7 @@ extern "C" int dsim_get_rng_states(dsim_handle h, uint64_t *st) {
 }
 
 extern "C" int dsim_rng_init_device(dsim_handle h, uint64_t seed) {
+  if (IS_MULTI(h)) h->seeded = true, h->states_given = false, h->seed_value = seed;
   MULTI_FORWARD(h, dsim_rng_init_device(s_, seed));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (((uint64_t)h->first + (uint64_t)h->n) >> 47) return fail(DSIM_ERR_INVALID, "walker index range too large");
@@ -546,7 +746,7 @@ extern "C" int dsim_rng_init_device(dsim_handle h, uint64_t seed) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h->staging, jt.cols.data(), bytes, hipMemcpyHostToDevice, h->stream));
   HostRng s = h_seed_state(seed);
-  rng_init_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(s.s0, s.s1, (uint64_t)h->first, h->n, (const uint64_t *)h->staging, jt.levels,
+  rng_init_kernel<<<grid_for(h->n, 256), 256, 0, h->stream>>>(s.s0, s.s1, (uint64_t)h->first, h->walker_ids, h->n, (const uint64_t *)h->staging, jt.levels,
                                                              h->s0[h->cur], h->s1[h->cur]);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -556,11 +756,11 @@ extern "C" int dsim_rng_init_device(dsim_handle h, uint64_t seed) {
 extern "C" int dsim_get_phases(dsim_handle h, double *phases) {
   if (IS_MULTI(h)) {
     if (!phases) return fail(DSIM_ERR_INVALID, "dsim_get_phases: null argument");
-    return multi_each(h, [&](int, dsim_sim *sh, int64_t off) -> int {
+    return multi_each(h, [&](int k_, dsim_sim *sh, int64_t off) -> int {
       std::vector<double> part((size_t)sh->M * (size_t)sh->n);
       const int rc = dsim_get_phases(sh, part.data());
       if (rc) return rc;
-      for (int m = 0; m < sh->M; m++) memcpy(phases + (size_t)m * (size_t)h->n + (size_t)off, part.data() + (size_t)m * (size_t)sh->n, (size_t)sh->n * sizeof(double));
+      for (int m = 0; m < sh->M; m++) shard_rows_out(h, k_, off, phases + (size_t)m * (size_t)h->n, 8, part.data() + (size_t)m * (size_t)sh->n, sh->n);
       return DSIM_OK;
     });
   }
@@ -577,11 +777,11 @@ extern "C" int dsim_get_phases(dsim_handle h, double *phases) {
 extern "C" int dsim_get_all_signals(dsim_handle h, double *signals) {
   if (IS_MULTI(h)) {
     if (!signals) return fail(DSIM_ERR_INVALID, "dsim_get_all_signals: null argument");
-    return multi_each(h, [&](int, dsim_sim *sh, int64_t off) -> int {
+    return multi_each(h, [&](int k_, dsim_sim *sh, int64_t off) -> int {
       std::vector<double> part((size_t)sh->M * (size_t)sh->n);
       const int rc = dsim_get_all_signals(sh, part.data());
       if (rc) return rc;
-      for (int m = 0; m < sh->M; m++) memcpy(signals + (size_t)m * (size_t)h->n + (size_t)off, part.data() + (size_t)m * (size_t)sh->n, (size_t)sh->n * sizeof(double));
+      for (int m = 0; m < sh->M; m++) shard_rows_out(h, k_, off, signals + (size_t)m * (size_t)h->n, 8, part.data() + (size_t)m * (size_t)sh->n, sh->n);
       return DSIM_OK;
     });
   }
@@ -640,7 +840,16 @@ extern "C" int dsim_get_all_signals(dsim_handle h, double *signals) {
 }
 
 extern "C" int dsim_get_iter_exc(dsim_handle h, uint8_t *exc) {
-  MULTI_FORWARD(h, exc ? dsim_get_iter_exc(s_, exc + off_) : fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument"));
+  if (IS_MULTI(h)) {
+    if (!exc) return fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument");
+    return multi_each(h, [&](int k, dsim_sim *sh, int64_t off) -> int {
+      if (h->shard_ids.empty()) return dsim_get_iter_exc(sh, exc + off);
+      std::vector<uint8_t> part((size_t)sh->n);
+      const int rc = dsim_get_iter_exc(sh, part.data());
+      if (rc == DSIM_OK) shard_rows_out(h, k, off, exc, 1, part.data(), sh->n);
+      return rc;
+    });
+  }
   if (!h || !exc) return fail(DSIM_ERR_INVALID, "dsim_get_iter_exc: null argument");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(exc, h->exc, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
@@ -1699,11 +1908,11 @@ static int check_recorded_range(dsim_sim *h, const char *who, int32_t t_begin, i
 
 /* steps [t_begin, t_end) of every shard's recording into one component-major block [step][3][n] of the whole handle */
 static int multi_get_recorded(dsim_sim *h, int32_t t_begin, int32_t t_end, double *out) {
-  return multi_each(h, [&](int, dsim_sim *sh, int64_t off) -> int {
+  return multi_each(h, [&](int k, dsim_sim *sh, int64_t off) -> int {
     std::vector<double> part((size_t)(t_end - t_begin) * 3 * (size_t)sh->n);
     const int rc = dsim_get_recorded(sh, t_begin, t_end, part.data());
     if (rc) return rc;
-    for (size_t r = 0; r < (size_t)(t_end - t_begin) * 3; r++) memcpy(out + r * (size_t)h->n + (size_t)off, part.data() + r * (size_t)sh->n, (size_t)sh->n * sizeof(double));
+    for (size_t r = 0; r < (size_t)(t_end - t_begin) * 3; r++) shard_rows_out(h, k, off, out + r * (size_t)h->n, 8, part.data() + r * (size_t)sh->n, sh->n);
     return DSIM_OK;
   });
 }
@@ -1956,6 +2165,7 @@ static int check_iter(int64_t max_iter, double eps) {
 }
 
 extern "C" int dsim_run_free(dsim_handle h, int32_t t_begin, int32_t t_end) {
+  if (IS_MULTI(h)) h->has_run = true;
   MULTI_FORWARD(h, dsim_run_free(s_, t_begin, t_end));
   WalkParams p = {};
   p.max_iter = 1;
@@ -1963,6 +2173,7 @@ extern "C" int dsim_run_free(dsim_handle h, int32_t t_begin, int32_t t_end) {
 }
 
 extern "C" int dsim_run_sphere(dsim_handle h, double radius, int64_t max_iter, double epsilon, int32_t t_begin, int32_t t_end) {
+  if (IS_MULTI(h)) h->has_run = true;
   MULTI_FORWARD(h, dsim_run_sphere(s_, radius, max_iter, epsilon, t_begin, t_end));
   if (!(radius > 0)) return fail(DSIM_ERR_INVALID, "radius must be > 0");
   int rc = check_iter(max_iter, epsilon);
@@ -1976,6 +2187,7 @@ extern "C" int dsim_run_sphere(dsim_handle h, double radius, int64_t max_iter, d
 
 extern "C" int dsim_run_cylinder(dsim_handle h, double radius, const double R[9], const double R_inv[9], int64_t max_iter,
                                  double epsilon, int32_t t_begin, int32_t t_end) {
+  if (IS_MULTI(h)) h->has_run = true;
   MULTI_FORWARD(h, dsim_run_cylinder(s_, radius, R, R_inv, max_iter, epsilon, t_begin, t_end));
   if (!(radius > 0) || !R || !R_inv) return fail(DSIM_ERR_INVALID, "bad cylinder arguments");
   int rc = check_iter(max_iter, epsilon);
@@ -1991,6 +2203,7 @@ extern "C" int dsim_run_cylinder(dsim_handle h, double radius, const double R[9]
 
 extern "C" int dsim_run_ellipsoid(dsim_handle h, const double semiaxes[3], const double R[9], const double R_inv[9],
                                   int64_t max_iter, double epsilon, int32_t t_begin, int32_t t_end) {
+  if (IS_MULTI(h)) h->has_run = true;
   MULTI_FORWARD(h, dsim_run_ellipsoid(s_, semiaxes, R, R_inv, max_iter, epsilon, t_begin, t_end));
   if (!semiaxes || !R || !R_inv) return fail(DSIM_ERR_INVALID, "bad ellipsoid arguments");
   int rc = check_iter(max_iter, epsilon);
@@ -2005,6 +2218,7 @@ extern "C" int dsim_run_ellipsoid(dsim_handle h, const double semiaxes[3], const
 }
 
 extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, double perm_prob, int32_t t_begin, int32_t t_end) {
+  if (IS_MULTI(h)) h->has_run = true;
   MULTI_FORWARD(h, dsim_run_mesh(s_, max_iter, epsilon, perm_prob, t_begin, t_end));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (!h->mesh.set) return fail(DSIM_ERR_STATE, "dsim_run_mesh called before dsim_set_mesh");
@@ -2089,7 +2303,7 @@ static int fill_open_impl(dsim_fill *fs, int64_t thread_begin, int intra, uint64
     hipError_t e = hipMemcpyAsync(cols, jt.cols.data(), jt.cols.size() * sizeof(HostRng), hipMemcpyHostToDevice, fs->stream);
     HostRng sd = h_seed_state(seed);
     if (e == hipSuccess) {
-      rng_init_kernel<<<grid_for(n, 256), 256, 0, fs->stream>>>(sd.s0, sd.s1, (uint64_t)thread_begin, n, cols, jt.levels, fs->s0, fs->s1);
+      rng_init_kernel<<<grid_for(n, 256), 256, 0, fs->stream>>>(sd.s0, sd.s1, (uint64_t)thread_begin, nullptr, n, cols, jt.levels, fs->s0, fs->s1);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(fs->stream);

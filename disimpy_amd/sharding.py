@@ -174,39 +174,91 @@ def _gather_rows(arr, dist, device=None):
 
 
 def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123, quiet=True, max_iter=int(1e3),
-                       epsilon=1e-13, dist=None, device=None, final_pos=False, all_signals=False):
+                       epsilon=1e-13, dist=None, device=None, final_pos=False, all_signals=False, traj=None):
     """``simulations.simulation`` with the walkers split over the ranks of the initialised process group (one process
     per GPU); every rank returns what the single-process call returns: the total signal (sum of cos(phase) per
     measurement) or, ``all_signals``, the (M, n_walkers) per-walker signals; with ``final_pos`` also the (n_walkers, 3)
     final positions - per-walker outputs gathered in walker order - and every rank raises the reference's warning
-    about walkers that exceeded ``max_iter`` with GLOBAL walker indices (disimpy/simulations.py:1406-1429).
+    about walkers that exceeded ``max_iter`` with GLOBAL walker indices (disimpy/simulations.py:1406-1429).  ``traj``:
+    rank 0 writes the reference's trajectories file (:1043-1048, :1194, :1211-1213), the ranks' columns gathered per range
+    of steps.  On a mesh the ranks cut the walkers by SPACE (include/dsim.h, dsim_partition_walkers: the Morton order of
+    the initial positions in equal parts; every rank computes the same cut), elsewhere by index; walker i keeps RNG
+    state i and position i either way and the outputs are the single-process bytes.
     (Inside one process ``simulations.simulation`` itself spreads the walkers over all visible GPUs; this entry is
     for jobs that are launched as one process per GPU.)"""
     import warnings
 
-    from . import simulations
+    from . import _lib, simulations
 
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    simulations._validate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, 128, max_iter)
+    simulations._validate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, 128, max_iter)
     np.random.seed(seed)
     a, b = shard_range(n_walkers, rank, world)
     M = gradient.shape[0]
+    ids_all = None  # mesh, several ranks: the walkers of every rank (ascending), a spatial cut
+    kw = {}
+    if world > 1 and substrate.type == "mesh":
+        # every rank needs all initial positions for the cut; the shared fill ends in an all-gather of the rows anyway
+        positions_all, _ = simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (0, n_walkers), dist=dist)
+        ids_all = _lib.partition_walkers(positions_all, world)
+        kw = {"walker_ids": ids_all[rank], "positions_all": positions_all}
+        a, b = 0, len(ids_all[rank])
+    lines = {"first": True}
+
+    def traj_sink(t0, t1, rows):
+        """this rank's (steps, n_local, 3) -> whole lines on rank 0"""
+        if t0 == 0 and lines["first"]:
+            lines["first"] = False
+            start = kw["positions_all"] if ids_all is not None else None
+            if start is None:  # the ranks' initial rows in walker order
+                mine = simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, shard_range(n_walkers, rank, world))[0]
+                mine = np.zeros((b - a, 3)) if mine is None else np.asarray(mine, dtype=np.float64)
+                start = _gather_rows(mine, dist, device) if world > 1 else mine
+            if rank == 0:
+                _lib.write_traj_line(traj, np.ascontiguousarray(start, dtype=np.float64), append=False)
+        cols = np.ascontiguousarray(rows.transpose(1, 0, 2))  # (n_local, steps, 3): the gather runs over walkers
+        whole = _gather_rows(cols, dist, device) if world > 1 else cols
+        if rank == 0:
+            if ids_all is not None:
+                out = np.empty_like(whole)
+                out[np.concatenate(ids_all)] = whole
+                whole = out
+            for k in range(t1 - t0):
+                _lib.write_traj_line(traj, np.ascontiguousarray(whole[:, k, :]), append=True)
+
     if b == a:  # more ranks than walkers: nothing to simulate here, but the collectives still need this rank
-        if world > 1 and substrate.type == "mesh" and isinstance(substrate.init_pos, str) and substrate.init_pos in ("intra", "extra"):
+        if world > 1 and ids_all is None and substrate.type == "mesh" and isinstance(substrate.init_pos, str) and substrate.init_pos in ("intra", "extra"):
             simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (a, b), dist=dist)  # the shared fill
         res = {"cos": np.zeros(M), "sin": np.zeros(M), "n_exceeded": 0, "iter_exc": np.zeros(0, dtype=bool),
                "all_signals": np.zeros((M, 0)), "positions": np.zeros((0, 3)), "limbs": np.zeros(4 * M, dtype=np.int64)}
+        if traj:  # take part in the gathers of every range of steps
+            n_t = gradient.shape[1]
+            chunk = max(1, min(n_t, (1 << 30) // (24 * max(1, n_walkers))))
+            for t0 in range(0, n_t, chunk):
+                traj_sink(t0, min(n_t, t0 + chunk), np.zeros((min(n_t, t0 + chunk) - t0, 0, 3)))
     else:
-        res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, None, quiet, max_iter, epsilon,
-                                    device=device or 0, walker_range=(a, b), dist=dist if world > 1 else None,
-                                    need_phases=bool(all_signals), need_positions=bool(final_pos))
+        res = simulations._simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon,
+                                    device=device or 0, walker_range=None if ids_all is not None else (a, b),
+                                    dist=dist if world > 1 and ids_all is None else None,
+                                    need_phases=bool(all_signals), need_positions=bool(final_pos),
+                                    traj_sink=traj_sink if traj else None, **kw)
     if "limbs" in res:  # the exact integer sums of the device reduction: the total does not depend on the split
         c, s, nexc = reduce_signal_exact(res["limbs"], res["n_exceeded"], dist, device)
     else:
         c, s, nexc = reduce_signal(res["cos"], res["sin"], res["n_exceeded"], dist, device)
+
+    def in_walker_order(rows):
+        """per-walker rows of every rank, gathered in rank order -> walker order"""
+        whole = _gather_rows(rows, dist, device) if world > 1 else rows
+        if ids_all is None:
+            return whole
+        out = np.empty_like(whole)
+        out[np.concatenate(ids_all)] = whole
+        return out
+
     if nexc:  # rare: the flags of all walkers, for the warning text (same on every rank)
-        exc = _gather_rows(res["iter_exc"].astype(np.uint8), dist, device).astype(bool) if world > 1 else res["iter_exc"]
+        exc = in_walker_order(res["iter_exc"].astype(np.uint8)).astype(bool)
         if np.any(exc):
             warnings.warn(
                 "Maximum number of iterations was exceeded in the intersection "
@@ -214,10 +266,7 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
             )
     signals = c
     if all_signals:
-        signals = res["all_signals"]
-        if world > 1:
-            signals = np.ascontiguousarray(_gather_rows(np.ascontiguousarray(signals.T), dist, device).T)
+        signals = np.ascontiguousarray(in_walker_order(np.ascontiguousarray(res["all_signals"].T)).T)
     if final_pos:
-        pos = res["positions"] if world == 1 else _gather_rows(res["positions"], dist, device)
-        return signals, pos
+        return signals, in_walker_order(res["positions"])
     return signals

@@ -205,7 +205,7 @@ def _validate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         raise ValueError("Incorrect value (%s) for max_iter" % max_iter)
 
 
-def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=None, dist=None):
+def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=None, dist=None, devices=None):
     """Initial positions of the walkers [a, b) = ``walker_range`` (default: all) and the
     substrate's rotation frames.  Returns (positions (b - a, 3) or None for zeros, frames).
 
@@ -275,20 +275,32 @@ def _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1):
         sim.run_mesh(max_iter, epsilon, substrate.perm_prob, t0, t1)
 
 
+_MIN_WALKERS_PER_DEVICE = 65536
+
+
 def _default_devices(n_gpu):
     """The devices ``simulation()`` spreads its walkers over: every visible GPU, one balanced contiguous shard of
     the walkers each (dsim_create_multi), unless DSIM_DEVICES names a list (e.g. ``0,0``: two shards on device 0)."""
     env = os.environ.get("DSIM_DEVICES")
     if env:
         return [int(x) for x in env.split(",") if x.strip() != ""]
+    # a job launched as one process per GPU (torchrun: RANK / LOCAL_RANK / WORLD_SIZE are set) must not drive every GPU
+    # from every rank: such a process stays on its own device (sharding.simulation_sharded is the entry for those jobs)
+    if any(os.environ.get(k) for k in ("LOCAL_RANK", "RANK", "WORLD_SIZE")):
+        return [int(os.environ.get("LOCAL_RANK", "0")) % max(1, n_gpu)]
     return list(range(max(1, n_gpu)))
 
 
 def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon, device=0,
-              walker_range=None, need_phases=False, need_positions=False, dist=None, devices=None):
+              walker_range=None, need_phases=False, need_positions=False, dist=None, devices=None, walker_ids=None,
+              positions_all=None, traj_sink=None):
     """Run walkers [a, b) = ``walker_range`` (default: all) on one GPU, or - ``devices`` a list of more than one
-    device - cut into balanced shards over several GPUs behind one multi-device handle (include/dsim.h,
-    dsim_create_multi: the shards run concurrently, per-walker outputs come back in order).
+    device - cut into shards over several GPUs behind one multi-device handle (include/dsim.h,
+    dsim_create_multi: the shards run concurrently, per-walker outputs come back in order; a mesh run cuts them by
+    space).  ``walker_ids`` (ascending) instead of a range: this process's part of a spatial cut of ALL walkers
+    (sharding.simulation_sharded), ``positions_all`` then holds the initial positions of all of them.
+    ``traj_sink(t0, t1, rows)``: called per range of recorded steps with this shard's positions (t1 - t0, 3, n_local)
+    instead of writing the trajectories file here (the ranks of a sharded job gather their columns).
 
     Returns a dict with the device-reduced signal sums and, on request,
     per-walker outputs of this range.  Walker i always gets RNG state i and
@@ -296,23 +308,41 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
     per-walker results."""
     n_t = gradient.shape[1]
     a, b = (0, n_walkers) if walker_range is None else walker_range
+    if walker_ids is not None:
+        walker_ids = np.ascontiguousarray(walker_ids, dtype=np.int64)
+        a, b = 0, len(walker_ids)
     step_l = np.sqrt(6 * diffusivity * dt)
     if not quiet:
         print("Number of random walkers = %s" % n_walkers)
         print("Number of steps = %s" % n_t)
         print("Step length = %s m" % step_l)
         print("Step duration = %s s" % dt)
+    if devices is not None and len(devices) > 1 and not os.environ.get("DSIM_DEVICES"):
+        # a shard below ~65 000 walkers does not fill a GPU: a small run pays handle creations and mesh uploads for nothing
+        devices = list(devices)[: max(1, (b - a) // _MIN_WALKERS_PER_DEVICE)]
     if devices is not None and len(devices) >= 1:
         device = int(devices[0])
-    positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b), dist=dist)
+    if walker_ids is not None:
+        frames = _initial_positions(0, substrate, seed, True, device, (0, 0))[1] if substrate.type in ("cylinder", "ellipsoid") else None
+        positions = None if positions_all is None else np.ascontiguousarray(np.asarray(positions_all)[walker_ids], dtype=np.float64)
+    else:
+        positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b), dist=dist, devices=devices)
     with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a, devices=devices) as sim:
+        if walker_ids is not None:
+            sim.set_walker_ids(walker_ids)
         sim.rng_init_device(seed)
         if positions is not None:
-            sim.set_positions(np.ascontiguousarray(positions, dtype=np.float64))
+            pos = np.ascontiguousarray(positions, dtype=np.float64)
+            if substrate.type == "mesh":
+                # several devices: every shard gets a REGION of the substrate (the Morton order of the initial positions
+                # cut into equal counts), not a range of walker indices - the outputs are the same bytes either way
+                sim.partition_by_position(pos)
+            else:
+                sim.set_positions(pos)
         if substrate.type == "mesh":
             sim.set_mesh(substrate.vertices, substrate.faces, substrate.xs, substrate.ys, substrate.zs,
                          substrate.n_sv, substrate.subvoxel_indices, substrate.triangle_indices)
-        if traj:
+        if traj and traj_sink is None:
             _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions))
         if traj:
             # the trajectories file needs the positions after every step: the device records them
@@ -321,6 +351,8 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             # <= 8 GB of recorded positions per range (a mesh run re-sorts its walkers inside a range like any other mesh
             # run - the device records through the slot -> walker map - so the ranges need not be short)
             chunk = max(1, min(n_t, (1 << 33) // (24 * max(1, b - a))))
+            if traj_sink is not None:  # the ranks gather whole lines: <= 1 GB of all walkers' positions per range
+                chunk = max(1, min(n_t, (1 << 30) // (24 * max(1, n_walkers))))
         elif quiet:
             chunk = n_t
         else:
@@ -335,7 +367,9 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
             t1 = min(n_t, t0 + chunk)
             _run_range(sim, substrate, frames, max_iter, epsilon, t0, t1)
             ms_total += sim.last_run_ms()[0]
-            if traj:
+            if traj and traj_sink is not None:
+                traj_sink(t0, t1, sim.recorded(t0, t1))
+            elif traj:
                 sim.write_traj(traj, t0, t1)
             if not quiet:
                 sys.stdout.write(f"\r{np.round((t0 / n_t) * 100, 1)}%")

@@ -120,6 +120,26 @@ int dsim_destroy(dsim_handle h);
 /* Initial positions, (n_walkers,3) row-major (cuda.to_device(positions), e.g. :1195). */
 int dsim_set_positions(dsim_handle h, const double *positions_aos);
 
+/* [r5] dsim_set_positions that also cuts the walkers of a multi-device handle (dsim_create_multi) into its shards by
+ * SPACE: the walkers are ordered along the Morton curve of the positions and shard k takes the k-th stretch of that
+ * order (as many walkers as it had), so that every GPU works in its own part of a mesh substrate instead of at 1/G
+ * of the walker density all over it.  The reference has no counterpart (simulations.py:1051 is one GPU).  Walker i
+ * keeps RNG state i and position i, host arrays stay in walker order, the exact signal sums do not depend on the cut:
+ * every output is the bytes of the contiguous cut.  Before the first dsim_run_* call only; RNG states seeded or given
+ * earlier are re-seeded / moved.  Single-device handle: the same as dsim_set_positions. */
+int dsim_partition_by_position(dsim_handle h, const double *positions_aos);
+
+/* The cut itself, host only: the walkers ordered along the Morton curve of their positions (21 bits per axis over the
+ * bounding box of the finite coordinates, ties by index), part k = the k-th stretch of that order with the balanced sizes
+ * of the contiguous cut.  ids_out (n): the walkers of part 0 ascending, then part 1, ...; part_start (n_parts + 1).
+ * Deterministic: every process of a job launched as one process per GPU computes the same cut. */
+int dsim_partition_walkers(const double *positions_aos, int64_t n_walkers, int32_t n_parts, int64_t *ids_out, int64_t *part_start);
+
+/* Single-device handle that holds such a part: slot i is walker first_walker + ids[i] (ascending, n of the handle;
+ * NULL: the range again).  dsim_rng_init_device seeds slot i with the state of ITS walker; every other entry point
+ * is per slot.  (Multi-device handles keep their own lists: dsim_partition_by_position.) */
+int dsim_set_walker_ids(dsim_handle h, const int64_t *ids);
+
 /* Upload RNG states produced by dsim_rng_init: n_walkers pairs {s0,s1}. */
 int dsim_set_rng_states(dsim_handle h, const uint64_t *states);
 

@@ -79,6 +79,22 @@ def test_trajectories_file_of_a_multi_shard_run_is_the_same_file(mods, tmp_path)
     assert len(files[0].splitlines()) == 41 and files[0] == files[1]
 
 
+def test_mesh_run_cut_by_space_writes_the_same_trajectories_file(mods, tmp_path):
+    """simulation() on a mesh over three shards: the walkers are cut by space (a shard owns a region), the trajectories
+    file, final positions and per-walker signals are the single-shard bytes"""
+    _lib, gradients, simulations, substrates = mods
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 50, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="intra", n_sv=np.array([6, 6, 6]), quiet=True)
+    n = 2003
+    out = []
+    for devices in ("0", "0,0,0"):
+        path = str(tmp_path / ("traj_mesh_%d.txt" % len(out)))
+        (sig, pos), _ = _run(simulations, devices, n, gradient, dt, sub, {}, traj=path, final_pos=True, all_signals=True)
+        out.append((open(path, "rb").read(), sig.tobytes(), pos.tobytes()))
+    assert len(out[0][0].splitlines()) == 51 and out[0] == out[1]
+
+
 def test_multi_device_handle_state_round_trips(mods):
     """the handle's host arrays cover all walkers in order: every shard reads / fills its slice (ragged split, more
     shards than walkers)"""
@@ -94,6 +110,8 @@ def test_multi_device_handle_state_round_trips(mods):
             for sim in (multi, one):
                 sim.rng_init_device(99)
                 sim.set_positions(pos)
+            if n > 2:  # the shards cut by space instead of by index (dsim_partition_by_position): the same bytes everywhere below
+                multi.partition_by_position(pos)
             np.testing.assert_array_equal(multi.positions(), pos)
             np.testing.assert_array_equal(multi.rng_states(), one.rng_states())
             st = one.rng_states()[::-1].copy()

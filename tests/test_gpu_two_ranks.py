@@ -30,6 +30,12 @@ def _case(name):
         gradient, dt = np.ascontiguousarray(gradient[:, :500]), dt
         v, f = bench.packed_cylinders()
         return 8192 + 77, gradient, dt, substrates.mesh(v, f, True, init_pos="uniform", quiet=True)
+    if name == "mesh_outputs":  # walkers placed by the (shared) device fill, every output of simulation()
+        gradient, dt = gradients.pgse(10e-3, 40e-3, 60, np.array([1e9, 3e8]), np.array([[1.0, 0, 0], [0, 1.0, 0]]))
+        m = np.load(os.path.join(ROOT, "tests", "golden", "sphere_mesh.npz"))
+        sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="intra", n_sv=np.array([6, 6, 6]),
+                              quiet=True)
+        return 3001, gradient, dt, sub
     raise ValueError(name)
 
 
@@ -66,6 +72,12 @@ def _rank_main(rank, world, port, name, q, backend="gloo"):
             n, sub = _fill_case()
             rows = simulations._fill_mesh(n, sub, True, 123, device=device, dist=dist, walker_range=sharding.shard_range(n, rank, world))
             q.put((rank, rows, None))
+        elif name.startswith("mesh_outputs"):
+            n, gradient, dt, sub = _case("mesh_outputs")
+            path = name.split("|", 1)[1]
+            sig, pos = sharding.simulation_sharded(n, D, gradient, dt, sub, seed=123, dist=dist, device=device, final_pos=True,
+                                                   all_signals=True, traj=path)
+            q.put((rank, (np.asarray(sig), np.asarray(pos)), None))
         else:
             n, gradient, dt, sub = _case(name)
             sig = sharding.simulation_sharded(n, D, gradient, dt, sub, seed=123, dist=dist, device=device)
@@ -107,6 +119,37 @@ def test_two_product_ranks_equal_one(name, rank_spawner):
         np.testing.assert_array_equal(sig, one)  # exact integer sums all-reduced: the bytes of the one-rank run
     np.testing.assert_array_equal(got[0][1], got[1][1])  # every rank holds the same total
     assert np.all(np.abs(one) <= n) and np.all(np.abs(one) > 0)
+
+
+def test_two_ranks_on_a_mesh_cut_by_space_return_every_output_and_the_trajectories_file(rank_spawner, tmp_path):
+    """a job of one process per GPU on a mesh: the ranks share the fill, cut the walkers by SPACE (dsim_partition_walkers:
+    each rank seeds ITS walkers through dsim_set_walker_ids) and return all_signals / final_pos in walker order; rank 0
+    writes the trajectories file - all of it the single-process bytes"""
+    from disimpy_amd import simulations
+
+    ctx = rank_spawner
+    world = 2
+    q = ctx.Queue()
+    port = _free_port()
+    path = str(tmp_path / "traj_two_ranks.txt")
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, "mesh_outputs|" + path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, out, err in got:
+        assert err is None, "rank %d failed: %s" % (rank, err)
+    n, gradient, dt, sub = _case("mesh_outputs")
+    one_path = str(tmp_path / "traj_one.txt")
+    os.environ["DSIM_DEVICES"] = "0"
+    try:
+        sig1, pos1 = simulations.simulation(n, D, gradient, dt, sub, seed=123, quiet=True, final_pos=True, all_signals=True, traj=one_path)
+    finally:
+        del os.environ["DSIM_DEVICES"]
+    for rank, (sig, pos), _ in got:
+        assert sig.tobytes() == sig1.tobytes() and pos.tobytes() == pos1.tobytes()
+    assert open(path, "rb").read() == open(one_path, "rb").read()
 
 
 def test_two_ranks_share_the_mesh_fill(rank_spawner):

@@ -264,21 +264,46 @@ def test_a_failing_rank_ends_the_sharded_fill_on_every_rank(mode):
 
 
 def _oracle_simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet, max_iter, epsilon, device=0,
-                     walker_range=None, need_phases=False, need_positions=False, dist=None, devices=None):
-    """stand-in for simulations._simulate with the CPU oracle as the engine (sphere; walker i <- state i, position i)"""
+                     walker_range=None, need_phases=False, need_positions=False, dist=None, devices=None, walker_ids=None,
+                     positions_all=None, traj_sink=None):
+    """stand-in for simulations._simulate with the CPU oracle as the engine (sphere, or a mesh with given initial
+    positions; walker i <- state i, position i - by range or, ``walker_ids``, by a list of walkers)"""
     from disimpy_amd import simulations
-    from oracle.oracle import SPHERE, Oracle
+    from oracle.oracle import MESH, SPHERE, Oracle
 
-    a, b = walker_range
     o = Oracle(exact=True)
     step_l = float(np.sqrt(6 * diffusivity * dt))
-    pos = np.ascontiguousarray(simulations._fill_sphere(b, substrate.radius, simulations._host_rng(seed))[a:b])
-    st = o.rng_states(b, seed)[a:].copy()
-    ph, exc, _ = o.run(o.geom(SPHERE, radius=substrate.radius, max_iter=max_iter, epsilon=epsilon), gradient, dt, step_l, pos, st)
+    ids = np.arange(*walker_range) if walker_ids is None else np.asarray(walker_ids)
+    if substrate.type == "sphere":
+        g = o.geom(SPHERE, radius=substrate.radius, max_iter=max_iter, epsilon=epsilon)
+        pos = np.ascontiguousarray(simulations._fill_sphere(n_walkers, substrate.radius, simulations._host_rng(seed))[ids])
+    else:
+        ma = dict(vertices=substrate.vertices, faces=substrate.faces, xs=substrate.xs, ys=substrate.ys, zs=substrate.zs, n_sv=substrate.n_sv,
+                  subvoxel_indices=substrate.subvoxel_indices, triangle_indices=substrate.triangle_indices)
+        g = o.geom(MESH, mesh=ma, max_iter=max_iter, epsilon=epsilon)
+        pos = np.ascontiguousarray(np.asarray(substrate.init_pos if positions_all is None else positions_all)[ids], dtype=np.float64)
+    st = o.rng_states(n_walkers, seed)[ids].copy()
+    pos0 = pos.copy()
+    ph, exc, tr = o.run(g, gradient, dt, step_l, pos, st, want_traj=bool(traj))
+    if traj and traj_sink is not None:
+        traj_sink(0, gradient.shape[1], tr)
+    elif traj:
+        simulations._write_traj_python(traj, "w", pos0)
+        for row in tr:
+            simulations._write_traj_python(traj, "a", row)
     c, s = o.signal(ph, exc)
     sig = np.cos(ph)
     sig[:, exc.astype(bool)] = np.nan
-    return {"cos": c, "sin": s, "n_exceeded": int(exc.sum()), "iter_exc": exc.astype(bool), "all_signals": sig, "positions": pos}
+    # the exact integer sums the device returns (dsim_get_signal_limbs): terms rounded to multiples of 2^-60, q = hi * 2^30 + lo
+    limbs = np.zeros(4 * ph.shape[0], dtype=np.int64)
+    keep = ~exc.astype(bool)
+    for m in range(ph.shape[0]):
+        for k, f in enumerate((np.cos, np.sin)):
+            terms = f(ph[m][keep & ~np.isnan(ph[m])])
+            q = sum(int(v) for v in np.rint(terms * 2.0**60))
+            limbs[4 * m + 2 * k], limbs[4 * m + 2 * k + 1] = q >> 30, q & ((1 << 30) - 1)
+    return {"cos": c, "sin": s, "n_exceeded": int(exc.sum()), "iter_exc": exc.astype(bool), "all_signals": sig, "positions": pos,
+            "limbs": limbs}
 
 
 def _worker_outputs(rank, world, port, n, max_iter, q):
@@ -330,3 +355,63 @@ def test_sharded_simulation_returns_every_per_walker_output(world, n, max_iter):
         else:
             assert not warned
     assert max_iter > 1 or one["n_exceeded"] > 0  # the max_iter = 1 case does exercise the warning
+
+
+def _small_mesh_substrate(n):
+    """a closed sphere mesh with n given initial positions inside it (no device fill needed)"""
+    from disimpy_amd import substrates
+
+    m = np.load(os.path.join(ROOT, "tests", "golden", "sphere_mesh.npz"))
+    rng = np.random.RandomState(11)
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, n_sv=np.array([4, 4, 4]), quiet=True)
+    centre, radius = 0.5 * np.asarray(sub.voxel_size), 0.4 * (np.min(sub.voxel_size) - 2e-6)
+    d = rng.standard_normal((n, 3))
+    d *= (radius * rng.uniform(0, 1, (n, 1)) ** (1 / 3)) / np.linalg.norm(d, axis=1)[:, None]
+    sub.init_pos = centre + d
+    return sub
+
+
+def _worker_traj(rank, world, port, n, kind, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from disimpy_amd import gradients, sharding, simulations, substrates
+
+    simulations._simulate = _oracle_simulate
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 25, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    sub = substrates.sphere(2e-6) if kind == "sphere" else _small_mesh_substrate(n)
+    sig, pos = sharding.simulation_sharded(n, 2e-9, gradient, dt, sub, seed=7, dist=dist, final_pos=True, all_signals=True, traj=path)
+    q.put((rank, sig, pos))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,kind", [(2, 57, "sphere"), (3, 64, "mesh"), (3, 2, "sphere")])
+def test_sharded_simulation_writes_the_trajectories_file_and_cuts_a_mesh_by_space(world, n, kind, tmp_path):
+    """traj= of a job of one process per GPU (disimpy/simulations.py:1043-1048, :1194, :1211-1213): rank 0 writes the
+    single-process file, the ranks' columns gathered per range of steps; on a mesh the ranks own REGIONS (the Morton
+    order of the initial positions in equal parts, dsim_partition_walkers) and every per-walker output still comes back
+    in walker order"""
+    from disimpy_amd import gradients, substrates
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    path = str(tmp_path / "traj_sharded.txt")
+    procs = [ctx.Process(target=_worker_traj, args=(r, world, port, n, kind, path, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 25, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    sub = substrates.sphere(2e-6) if kind == "sphere" else _small_mesh_substrate(n)
+    want_path = str(tmp_path / "traj_one.txt")
+    one = _oracle_simulate(n, 2e-9, gradient, dt, sub, 7, want_path, True, 1000, 1e-13, walker_range=(0, n))
+    for rank, sig, pos in got:
+        np.testing.assert_array_equal(sig, one["all_signals"])
+        np.testing.assert_array_equal(pos, one["positions"])
+    assert open(path, "rb").read() == open(want_path, "rb").read()
+    assert len(open(path).read().splitlines()) == 26
