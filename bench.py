@@ -282,33 +282,65 @@ def snapshot_sample(sim, idx):
     return dict(pos=sim.positions()[idx], ph=sim.phases()[:, idx], st=sim.rng_states()[idx], exc=np.asarray(sim.iter_exc())[idx])
 
 
-def check_sample_of_timed_run(w, positions, first_walker, idx, snap):
-    """The run bench.py TIMES, pinned: `snap` holds 512 walkers spread over rank 0's shard as the first (warm-up) pass
-    over the waveform left them - the pass that starts from the initial state, after which the timed passes continue the
-    same walk.  The exact build of the CPU oracle runs those walkers alone from the same initial positions and RNG
-    states over all T steps (walkers are independent, so the sample pins the full-size run with everything it goes
-    through: walker groups, spatial sorts, per-walker clocks, restored order); bit-identity of positions, phases, RNG
-    states and iter_exc is reported as "identical"."""
+def check_sample_of_timed_run(w, positions, walkers, idx, snap_first, snap_last, n_passes):
+    """The run bench.py TIMES, pinned over ALL of its passes: 512 walkers spread over rank 0's shard, read back after the
+    first (warm-up) pass - the one that starts from the initial state - and again after the LAST timed pass.  The exact
+    build of the CPU oracle runs those walkers alone from the same initial positions and RNG states over all T steps of
+    every pass (warm-up + timed: the passes continue one walk; phases keep accumulating) and is compared at both points
+    (walkers are independent, so the sample pins the full-size run with everything it goes through: walker groups,
+    spatial sorts, per-walker clocks, restored order, shards cut by space); bit-identity of positions, phases, RNG states
+    and iter_exc is reported as "identical".  ``walkers``: the global walker index of each sampled slot; ``idx``: the
+    slots (rows of ``positions``, the shard's initial positions)."""
     from disimpy_amd import _lib
     from oracle.oracle import STATE_DTYPE, Oracle
 
     o = Oracle(exact=True)
     sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
     step_l = float(np.sqrt(6 * w["D"] * dt))
-    T = gradient.shape[1]
-    st0 = np.concatenate([_lib.rng_init(123, int(first_walker + i), 1) for i in idx])
+    T, M = gradient.shape[1], gradient.shape[0]
+    st0 = np.concatenate([_lib.rng_init(123, int(i), 1) for i in walkers])
     st = np.zeros(len(idx), dtype=STATE_DTYPE)
     st["s0"], st["s1"] = st0[:, 0], st0[:, 1]
     pos = np.zeros((len(idx), 3)) if sub.type == "free" else np.ascontiguousarray(positions[idx], dtype=np.float64)
+    ph, exc = np.zeros((M, len(idx))), np.zeros(len(idx), dtype=np.uint8)
+    g = oracle_geometry(o, sub)
     t0 = time.perf_counter()
-    ph, exc, _ = o.run(oracle_geometry(o, sub), gradient, dt, step_l, pos, st, n_threads=os.cpu_count() or 1)
-    same = {"positions": bool(np.array_equal(pos, snap["pos"])), "phases": bool(np.array_equal(ph, snap["ph"])),
-            "rng_states": bool(np.array_equal(np.stack([st["s0"], st["s1"]], axis=1), snap["st"])),
-            "iter_exc": bool(np.array_equal(exc.astype(bool), snap["exc"].astype(bool)))}
-    return {"walkers": int(len(idx)), "steps": int(T), "of": "the first pass of this run (warm-up, from the initial state; the timed "
-            "passes continue it)", "result": "identical" if all(same.values()) else "DIFFERENT", "fields": same,
-            "max_abs_position_difference_m": float(np.max(np.abs(pos - snap["pos"]))) if len(idx) else 0.0,
+
+    def compare(snap):
+        same = {"positions": bool(np.array_equal(pos, snap["pos"])), "phases": bool(np.array_equal(ph, snap["ph"])),
+                "rng_states": bool(np.array_equal(np.stack([st["s0"], st["s1"]], axis=1), snap["st"])),
+                "iter_exc": bool(np.array_equal(exc.astype(bool), snap["exc"].astype(bool)))}
+        return {"result": "identical" if all(same.values()) else "DIFFERENT", "fields": same,
+                "max_abs_position_difference_m": float(np.max(np.abs(pos - snap["pos"]))) if len(idx) else 0.0}
+
+    first = last = None
+    for k in range(n_passes):
+        o.run(g, gradient, dt, step_l, pos, st, phases=ph, iter_exc=exc, n_threads=os.cpu_count() or 1)
+        if k == 0:
+            first = compare(snap_first)
+        if k == n_passes - 1 and snap_last is not None:
+            last = compare(snap_last)
+    ok = first["result"] == "identical" and (last is None or last["result"] == "identical")
+    return {"walkers": int(len(idx)), "steps": int(T), "passes": int(n_passes),
+            "of": "this run: after its first pass (warm-up, from the initial state) and after its last timed pass",
+            "result": "identical" if ok else "DIFFERENT", "after_first_pass": first, "after_last_pass": last,
             "oracle_s": time.perf_counter() - t0}
+
+
+def end_to_end(w, n_total, devices=None):
+    """Wall time of ONE simulations.simulation() call on the bench workload, set-up included (initial positions, handle,
+    RNG seeding, mesh index, the T steps, the signal) - the drop-in call a user of the reference makes
+    (disimpy/simulations.py:1051), against `ms_per_step` which times the steps alone with everything resident."""
+    from disimpy_amd import simulations
+
+    if devices is not None:
+        os.environ["DSIM_DEVICES"] = ",".join(str(d) for d in devices)
+    elif "DSIM_DEVICES" not in os.environ:
+        os.environ["DSIM_DEVICES"] = "0"
+    t = time.perf_counter()
+    sig = simulations.simulation(n_total, w["D"], w["gradient"], w["dt"], w["substrate"], seed=123, quiet=True)
+    el = time.perf_counter() - t
+    return {"simulation_call_s": el, "mean_S_over_N": float(np.mean(sig) / n_total), "devices": os.environ.get("DSIM_DEVICES")}
 
 
 def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
@@ -343,8 +375,12 @@ def run_steps(sim, sub, frames, T, n_steps, dist, device, fence, M=1):
     return time.perf_counter() - t0, walk_ms, run_ms, launches, sig
 
 
-def setup_sim(args, w, n_total, a, b, device, dist=None):
-    """Untimed set-up: everything resident in HBM.  Returns (sim, positions of [a, b), setup_s)."""
+def setup_sim(args, w, n_total, a, b, device, dist=None, devices=None, part=None):
+    """Untimed set-up: everything resident in HBM.  Returns (sim, positions of the shard's walkers, setup_s, ids).
+
+    The shard: walkers [a, b) - or, ``part`` = (k, G) on a mesh, the k-th of G parts of the SPATIAL cut of all n_total
+    walkers (dsim_partition_walkers: what a rank of a G-GPU job owns); ``ids`` are then its walkers, ascending (else
+    None).  ``devices``: a multi-device handle over these devices (dsim_create_multi; a mesh is cut by space inside)."""
     from disimpy_amd import _lib, simulations
 
     sub, gradient, dt = w["substrate"], w["gradient"], w["dt"]
@@ -359,35 +395,52 @@ def setup_sim(args, w, n_total, a, b, device, dist=None):
     setup["device_start"] = time.perf_counter() - t
     t = time.perf_counter()
     np.random.seed(123)
+    spatial = part is not None and sub.type == "mesh" and part[1] > 1
+    lo, hi = (0, n_total) if spatial else (a, b)
     cache = os.environ.get("DSIM_BENCH_POSITIONS_CACHE")  # development aid: A/B runs of kernel variants on one box
     if cache and os.path.exists(cache) and sub.type == "mesh":
-        positions, frames = np.load(cache)[a:b], None
+        positions, frames = np.load(cache)[lo:hi], None
     else:
-        positions, frames = simulations._initial_positions(n_total, sub, 123, True, device, (a, b), dist=dist)
-        if cache and sub.type == "mesh" and (a, b) == (0, n_total):
+        positions, frames = simulations._initial_positions(n_total, sub, 123, True, device, (lo, hi), dist=dist, devices=devices)
+        if cache and sub.type == "mesh" and (lo, hi) == (0, n_total):
             np.save(cache, positions)
     w["frames"] = frames
     setup["initial_positions"] = time.perf_counter() - t
+    ids = None
+    if spatial:
+        t = time.perf_counter()
+        cost = _lib.mesh_walker_cost(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices,
+                                     step_l, positions)
+        ids = _lib.partition_walkers(positions, part[1], cost)[part[0]]
+        positions = np.ascontiguousarray(positions[ids])
+        a, b = 0, len(ids)
+        setup["partition_by_space"] = time.perf_counter() - t
     if b == a:
-        return None, positions, setup
+        return None, positions, setup, ids
     t = time.perf_counter()
-    sim = _lib.Sim(b - a, gradient, dt, step_l, device=device, first_walker=a)
+    sim = _lib.Sim(b - a, gradient, dt, step_l, device=device, first_walker=a, devices=devices)
     sim.set_tuning(args.block_size, args.tile_steps, args.meas_per_pass, args.resort_steps, args.gradient_source,
                    args.mesh_traversal)
+    if ids is not None:
+        sim.set_walker_ids(ids)
     setup["create"] = time.perf_counter() - t
     t = time.perf_counter()
     sim.rng_init_device(123)
     setup["rng_init_device"] = time.perf_counter() - t
     t = time.perf_counter()
-    if positions is not None:
-        sim.set_positions(np.ascontiguousarray(positions, dtype=np.float64))
-    setup["upload_positions"] = time.perf_counter() - t
-    t = time.perf_counter()
-    if sub.type == "mesh":
+    if sub.type == "mesh":  # before the positions: a multi-device handle cuts its walkers by the cost the index implies
         sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices,
                      sub.triangle_indices)
     setup["mesh_index_upload"] = time.perf_counter() - t
-    return sim, positions, setup
+    t = time.perf_counter()
+    if positions is not None:
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        if sub.type == "mesh":
+            sim.partition_by_position(pos)  # a multi-device handle cuts its walkers by space; else = set_positions
+        else:
+            sim.set_positions(pos)
+    setup["upload_positions"] = time.perf_counter() - t
+    return sim, positions, setup, ids
 
 
 def kernel_name(sub, M, args):
@@ -420,20 +473,24 @@ def lib_sha256():
 
 def secondary_rates(args, device):
     """The other BASELINE configs at a glance (rank 0 of a single-GPU run, after the timed region):
-    C2 and C3 at their full sizes; C4 at the per-GPU shares of its 4- and 2-GPU configurations (2.5e6 and 5e6 of
-    1e7 walkers); the headline workload at the per-GPU share of the 8-GPU configuration (1.25e6 walkers)."""
+    C2 and C3 at their full sizes; C4 at the per-GPU shares of its 4- and 2-GPU configurations and the headline workload
+    at the per-GPU share of the 8-GPU configuration - the shares a GPU of those jobs actually gets: the FIRST of the G
+    parts of the SPATIAL cut of all 1e7 walkers (dsim_partition_walkers; rounds 1-4 ran the first n / G walkers of a
+    smaller fill, a random sample of the whole substrate)."""
     out = {}
-    for key, name, n, meas in (("c2", "c2", 1_000_000, 1), ("c3", "c3", 1_000_000, 1), ("c4_share_of_4_gpus", "c4", 2_500_000, 1),
-                               ("c4_share_of_2_gpus", "c4", 5_000_000, 1), ("c5b_share_of_8_gpus", "c5b", 1_250_000, 1)):
+    for key, name, n, meas, parts in (("c2", "c2", 1_000_000, 1, 1), ("c3", "c3", 1_000_000, 1, 1), ("c4_share_of_4_gpus", "c4", 10_000_000, 1, 4),
+                                      ("c4_share_of_2_gpus", "c4", 10_000_000, 1, 2), ("c5b_share_of_8_gpus", "c5b", 10_000_000, 1, 8)):
         w = make_workload(name, n, meas)
         sub, T = w["substrate"], w["gradient"].shape[1]
-        sim, _, _ = setup_sim(args, w, n, 0, n, device)
+        sim, _, _, ids = setup_sim(args, w, n, 0, n, device, part=(0, parts) if parts > 1 else None)
+        n_here = n if ids is None else len(ids)
         run_steps(sim, sub, w["frames"], T, 1, None, device, lambda: None)
         el, walk_ms, _, _, sig = run_steps(sim, sub, w["frames"], T, 2, None, device, lambda: None)
         sim.close()
-        walk_rate = n * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)
-        out[key] = {"workload": w["label"], "value": n * T * 2 / el, "unit": "spin-steps/s",
-                     "walk_kernel_spin_steps_per_s": walk_rate, "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=walk_rate)}
+        walk_rate = n_here * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)
+        out[key] = {"workload": w["label"], "walkers": n_here, "cut": "spatial part 1 of %d" % parts if parts > 1 else "all",
+                    "value": n_here * T * 2 / el, "unit": "spin-steps/s",
+                    "walk_kernel_spin_steps_per_s": walk_rate, "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=walk_rate)}
     return out
 
 
@@ -523,14 +580,21 @@ def main(argv=None):
     ap.add_argument("--gradient-source", type=int, default=0, help="1 = LDS tiles, 2 = scalar loads (0 = default)")
     ap.add_argument("--mesh-traversal", type=int, default=0, help="1 = per lane, 2 = wavefront-cooperative")
     ap.add_argument("--resort-steps", type=int, default=0, help="mesh: steps between walker re-sorts (0 auto, <0 never)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "inprocess"],
+                    help="--gpus N > 1: `ranks` = one process per GPU over torch.distributed (what the driver launches); "
+                         "`inprocess` = ONE process, the N devices behind one multi-device handle (dsim_create_multi) - the "
+                         "path simulations.simulation() takes on a node with several GPUs.  DSIM_DEVICES (e.g. 0,0,0,0) names "
+                         "the devices of the in-process mode explicitly")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the timed simulations.simulation() call (end_to_end_s)")
     args = ap.parse_args(argv)
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    inprocess = args.mode == "inprocess" and "WORLD_SIZE" not in os.environ
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not inprocess:
         return launch_ranks(args.gpus, argv)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = 1 if inprocess else int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus and not inprocess:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     # stdout carries ONE line, the JSON: whatever the communication libraries print while they start up (RCCL's
     # version banner, gloo's connection notes) goes to stderr - file descriptor 1 points there until the end
@@ -565,9 +629,17 @@ def main(argv=None):
     sub, gradient = w["substrate"], w["gradient"]
     M, T = gradient.shape[0], gradient.shape[1]
     a, b = sharding.shard_range(n_total, rank, world)
-    n_local = b - a
+    devices = None
+    if inprocess:
+        env = os.environ.get("DSIM_DEVICES")
+        devices = [int(x) for x in env.split(",") if x.strip() != ""] if env else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit("--gpus %d does not match DSIM_DEVICES=%s" % (args.gpus, env))
 
-    sim, positions, setup = setup_sim(args, w, n_total, a, b, device, dist)
+    # a mesh job of several ranks is cut by SPACE: rank r owns the r-th part of the Morton order of all initial positions
+    sim, positions, setup, ids = setup_sim(args, w, n_total, a, b, device, dist, devices=devices,
+                                           part=(rank, world) if world > 1 else None)
+    n_local = (b - a) if ids is None else len(ids)
     setup["workload_and_mesh_index_host"] = t_wl
     setup["total"] = sum(setup.values())
     frames = w["frames"]
@@ -584,12 +656,14 @@ def main(argv=None):
             # 512 walkers from all over the shard as the pass from the initial state left them: compared with the CPU
             # oracle after the timed region (check_sample_of_timed_run)
             idx = np.unique(np.linspace(0, n_local - 1, 512).astype(np.int64))
-            timed_sample = (idx, snapshot_sample(sim, idx))
+            timed_sample = [idx, snapshot_sample(sim, idx), None]
         if args.warmup > 1:
             run_steps(sim, sub, frames, T, args.warmup - 1, dist, device, fence, M)
     elapsed, walk_ms, run_ms, launches, sig = run_steps(sim, sub, frames, T, args.steps, dist, device, fence, M)
     if first_pass is None:
         first_pass = sig
+    if timed_sample is not None:  # the same walkers as the LAST timed pass left them
+        timed_sample[2] = snapshot_sample(sim, timed_sample[0])
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -660,13 +734,17 @@ def main(argv=None):
                 "of an LDS tile; LDS holds the log/cos tables, the subvoxel boundaries and the wave work queues.",
     }
     out = {
-        "metric": "spin-steps/sec", "value": value, "unit": "spin-steps/s", "n_gpus": world, "steps": args.steps,
+        "metric": "spin-steps/sec", "value": value, "unit": "spin-steps/s", "n_gpus": args.gpus if inprocess else world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": w["label"], "total_walkers": n_total, "walkers_per_gpu": n_local, "time_steps": T,
             "measurements": M, "substrate": sub.type, "triangles": int(len(sub.faces)) if sub.type == "mesh" else 0,
-            "seed": 123, "sharding": "balanced walker ranges, 1 all-reduce of 4M+1 int64 (exact signal sums) per step (%s)" % args.backend,
+            "seed": 123, "mode": "inprocess (dsim_create_multi over devices %s)" % devices if inprocess else "ranks",
+            "n_devices": len(devices) if inprocess else world,
+            "sharding": ("walkers cut by space (Morton order of the initial positions in equal parts)" if sub.type == "mesh" else
+                         "balanced walker ranges") + (", exact integer signal sums added inside the handle" if inprocess else
+                                                       ", 1 all-reduce of 4M+1 int64 (exact signal sums) per step (%s)" % args.backend),
         },
         "roofline": roofline,
         "walk_kernel_spin_steps_per_s": n_local * T / (walk_ms_step * 1e-3),
@@ -683,11 +761,15 @@ def main(argv=None):
     if rank == 0 and not args.no_signal_check:
         out["signal_rel_err"] = signal_rel_err(w, positions, device)
         out["signal_rel_err"]["sample_of_timed_run"] = (
-            check_sample_of_timed_run(w, positions, a, *timed_sample) if timed_sample is not None else
-            "not taken (needs --warmup >= 1: the first pass starts from the initial state)")
+            check_sample_of_timed_run(w, positions, (a + timed_sample[0]) if ids is None else ids[timed_sample[0]], timed_sample[0],
+                                      timed_sample[1], timed_sample[2], args.warmup + args.steps)
+            if timed_sample is not None else "not taken (needs --warmup >= 1: the first pass starts from the initial state)")
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(w, positions)
-    if rank == 0 and not args.no_secondary and world == 1:
+    if rank == 0 and not args.no_end_to_end and world == 1:
+        out["end_to_end_s"] = end_to_end(w, n_total, devices)
+        out["end_to_end_s"]["timed_region_equivalent_s"] = elapsed / args.steps
+    if rank == 0 and not args.no_secondary and world == 1 and not inprocess:
         out["secondary"] = secondary_rates(args, device)
     if dist is not None:
         dist.barrier()

@@ -21,7 +21,7 @@ SYMBOLS = (
     "dsim_last_run_ms", "dsim_last_walk_ms", "dsim_last_walk_busy_ms", "dsim_set_tuning", "dsim_set_recording", "dsim_get_recorded",
     "dsim_write_traj", "dsim_write_traj_line", "dsim_get_all_signals", "dsim_fill_open", "dsim_fill_run", "dsim_fill_close", "dsim_mesh_fine_grid",
     "dsim_create_multi", "dsim_shard_count", "dsim_get_signal_limbs", "dsim_signal_from_limbs", "dsim_partition_by_position",
-    "dsim_partition_walkers", "dsim_set_walker_ids",
+    "dsim_partition_walkers", "dsim_set_walker_ids", "dsim_fill_mesh_multi", "dsim_mesh_walker_cost",
 )  # fmt: skip
 
 _f64p = C.POINTER(C.c_double)
@@ -72,7 +72,9 @@ def load():
     lib.dsim_destroy.argtypes = [_h]
     lib.dsim_set_positions.argtypes = [_h, _f64p]
     lib.dsim_partition_by_position.argtypes = [_h, _f64p]
-    lib.dsim_partition_walkers.argtypes = [_f64p, C.c_int64, C.c_int32, _i64p, _i64p]
+    lib.dsim_partition_walkers.argtypes = [_f64p, C.c_int64, C.c_int32, _f64p, _i64p, _i64p]
+    lib.dsim_mesh_walker_cost.argtypes = [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, C.c_double,
+                                          _f64p, C.c_int64, _f64p]
     lib.dsim_set_walker_ids.argtypes = [_h, _i64p]
     lib.dsim_set_rng_states.argtypes = [_h, _u64p]
     lib.dsim_set_mesh.argtypes = [_h, _f64p, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p,
@@ -92,6 +94,8 @@ def load():
     lib.dsim_get_rng_states.argtypes = [_h, _u64p]
     lib.dsim_fill_mesh.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_uint64, _f64p, C.c_int64, _i64p, C.c_int64,
                                    _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, _f64p]
+    lib.dsim_fill_mesh_multi.argtypes = [_i32p, C.c_int32, C.c_int64, C.c_int, C.c_uint64, _f64p, C.c_int64, _i64p, C.c_int64,
+                                         _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64, _f64p]
     lib.dsim_fill_open.argtypes = [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_uint64, _f64p, C.c_int64, _i64p,
                                    C.c_int64, _f64p, _f64p, _f64p, _f64p, _i64p, _i64p, _i64p, C.c_int64]
     lib.dsim_fill_run.argtypes = [_h, C.c_int64, _i64p, _f64p, C.c_int64, _i64p]
@@ -211,14 +215,31 @@ def mesh_fine_grid(vertices, faces, xs, ys, zs, n_sv, subvoxel_indices, triangle
                 box=box[: nr.value], packed=packed[: nr.value], quantum=float(quantum[0]))
 
 
-def partition_walkers(positions, n_parts):
+def partition_walkers(positions, n_parts, weights=None):
     """The walkers cut into n_parts by space (include/dsim.h, dsim_partition_walkers; host only).  Returns the list of
-    the parts' walker indices (each ascending) - balanced sizes, Morton order of the positions."""
+    the parts' walker indices (each ascending) - Morton order of the positions, balanced counts or, with ``weights``,
+    equal total weight."""
     pos = _c(positions, np.float64)
     n = len(pos)
     ids, start = np.zeros(max(n, 1), dtype=np.int64), np.zeros(n_parts + 1, dtype=np.int64)
-    check(load().dsim_partition_walkers(p_f64(pos), n, int(n_parts), p_i64(ids), p_i64(start)))
+    w = None if weights is None else _c(weights, np.float64)
+    assert w is None or w.shape == (n,)
+    check(load().dsim_partition_walkers(p_f64(pos), n, int(n_parts), None if w is None else p_f64(w), p_i64(ids), p_i64(start)))
     return [ids[start[k]: start[k + 1]].copy() for k in range(n_parts)]
+
+
+def mesh_walker_cost(vertices, faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, step_l, positions):
+    """Estimated relative cost of a walker-step at every position of a mesh substrate (include/dsim.h,
+    dsim_mesh_walker_cost; host only): the weights of the spatial cut."""
+    v, f = _c(vertices, np.float64), _c(faces, np.int64)
+    xs, ys, zs = _c(xs, np.float64), _c(ys, np.float64), _c(zs, np.float64)
+    nsv = _c(n_sv, np.int64)
+    svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
+    pos = _c(positions, np.float64)
+    out = np.zeros(len(pos))
+    check(load().dsim_mesh_walker_cost(p_f64(v), len(v), p_i64(f), len(f), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri),
+                                       len(tri), float(step_l), p_f64(pos), len(pos), p_f64(out)))
+    return out
 
 
 def triangle_box_overlap(triangle, box):
@@ -430,7 +451,9 @@ def write_traj_line(path, positions, append=False):
 
 
 def fill_mesh(n_points, intra, seed, vertices, faces, voxel_size, xs, ys, zs, n_sv, subvoxel_indices,
-              triangle_indices, device=0):
+              triangle_indices, device=0, devices=None):
+    """disimpy/simulations.py:505-579 on the device; ``devices`` (a list, entries may repeat): the threads of every launch
+    split over them (dsim_fill_mesh_multi) - the same rows"""
     lib = load()
     if lib.dsim_device_count() <= 0:
         raise DsimError("no HIP device visible (need an AMD GPU with ROCm); there is no CPU fallback")
@@ -440,6 +463,12 @@ def fill_mesh(n_points, intra, seed, vertices, faces, voxel_size, xs, ys, zs, n_
     nsv = _c(n_sv, np.int64)
     svi, tri = _c(subvoxel_indices, np.int64), _c(triangle_indices, np.int64)
     out = np.zeros((n_points, 3))
+    if devices is not None and len(devices) > 1:
+        ids = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib.dsim_fill_mesh_multi(ids.ctypes.data_as(_i32p), len(ids), n_points, int(bool(intra)), seed, p_f64(v), len(v),
+                                       p_i64(f), len(f), p_f64(vs), p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi),
+                                       p_i64(tri), len(tri), p_f64(out)))
+        return out
     check(lib.dsim_fill_mesh(device, n_points, int(bool(intra)), seed, p_f64(v), len(v), p_i64(f), len(f), p_f64(vs),
                              p_f64(xs), p_f64(ys), p_f64(zs), p_i64(nsv), p_i64(svi), p_i64(tri), len(tri),
                              p_f64(out)))

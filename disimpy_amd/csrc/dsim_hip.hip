@@ -259,6 +259,12 @@ struct dsim_sim {
   int64_t *walker_ids = nullptr;
   bool seeded = false, states_given = false, has_run = false; /* what a re-partition would have to redo */
   uint64_t seed_value = 0;
+  /* what it takes to create a shard again with another number of walkers (dsim_partition_by_position cuts a mesh into
+   * parts of equal estimated COST, not of equal counts): the gradient, the tuning, the recording switch */
+  std::vector<double> keep_g[3];
+  int keep_tune[6] = {0, 0, 0, 0, 0, 0};
+  bool keep_recording = false;
+  std::shared_ptr<const HostMesh> host_mesh; /* the index of dsim_set_mesh as built on the host: the cost model looks cells up in it */
 };
 
 /* f(k, shard, first walker of the shard inside the handle) for every shard of a multi-device handle, concurrently (one
@@ -468,6 +474,11 @@ extern "C" int dsim_create_multi(dsim_handle *out, const int32_t *device_ids, in
   h->T = T;
   h->dt = dt;
   h->step_l = step_l;
+  if (M > 0 && T > 0 && gx && gy && gz) {
+    h->keep_g[0].assign(gx, gx + (size_t)M * T);
+    h->keep_g[1].assign(gy, gy + (size_t)M * T);
+    h->keep_g[2].assign(gz, gz + (size_t)M * T);
+  }
   /* balanced contiguous ranges: the first n % G shards own one walker more (disimpy_amd/sharding.py, shard_range) */
   const int64_t base = n_walkers / n_devices, extra = n_walkers % n_devices;
   for (int k = 0; k < n_devices; k++) {
@@ -492,6 +503,11 @@ extern "C" int dsim_shard_count(dsim_handle h) { return h ? (IS_MULTI(h) ? (int)
 
 extern "C" int dsim_set_tuning(dsim_handle h, int32_t block_size, int32_t tile_steps, int32_t meas_per_pass, int32_t resort_steps,
                                int32_t gradient_source, int32_t mesh_traversal) {
+  if (IS_MULTI(h)) {
+    const int v[6] = {block_size, tile_steps, meas_per_pass, resort_steps, gradient_source, mesh_traversal};
+    for (int q = 0; q < 6; q++)
+      if (v[q]) h->keep_tune[q] = v[q];
+  }
   MULTI_FORWARD(h, dsim_set_tuning(s_, block_size, tile_steps, meas_per_pass, resort_steps, gradient_source, mesh_traversal));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   if (block_size) {
@@ -532,15 +548,85 @@ extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
   return DSIM_OK;
 }
 
-/* [r5] Walkers cut into n_shards parts by SPACE: the walkers are ordered along the Morton curve of `pos` (21 bits per
- * axis, cubic cells over the bounding box of the finite coordinates; ties by walker index) and part k is the k-th stretch of that
- * order, of the balanced sizes of the contiguous cut (the first n % n_shards parts hold one walker more).  ids_out
- * (n): the walkers of part 0 in ascending order, then those of part 1, ...; part_start (n_shards + 1): where each part
- * begins in ids_out.  Host only, deterministic - every rank of a job computes the same cut from the same positions. */
-extern "C" int dsim_partition_walkers(const double *pos, int64_t n, int32_t n_shards, int64_t *ids_out, int64_t *part_start) {
-  if (!pos || !ids_out || !part_start || n < 0 || n_shards < 1) return fail(DSIM_ERR_INVALID, "dsim_partition_walkers: bad argument");
-  const size_t G = (size_t)n_shards;
-  const int64_t base = n / n_shards, extra = n % n_shards;
+/* Estimated relative cost of a walker-step at the walker's position in a mesh: 1 + c x (records of the fine cell the
+ * position lies in, at most 40).  The records are what a pass of the traversal has to test; a walker in an empty
+ * cell - the inside of a soma - finishes its steps in one cheap pass.  c = 0.07 from the measured rates of the eight
+ * equal-count parts of the refined neuron (1.43e10 in the dendrites, 2.05e10 in the soma) and of the parts cut with
+ * c = 0.06 (profiles/history/r05_spatial_parts.txt); DSIM_COST_PER_RECORD overrides it in tuning runs.  Only the CUT depends on
+ * it, never a result. */
+static void mesh_walker_cost(const HostMesh &hm, const double *pos, int64_t n, double *w) {
+  double c = 0.07;
+  if (const char *e = getenv("DSIM_COST_PER_RECORD")) c = atof(e);
+  const int lk = hm.lk, k = 1 << lk, ku = lk > 0 ? 2 * k : 1;
+  const int per[3] = {ku, ku, k};
+  const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n / 65536));
+  auto work = [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; i++) {
+      int sv[3], cell[3];
+      bool ok = true;
+      for (int ax = 0; ax < 3 && ok; ax++) {
+        const double t = (pos[3 * i + ax] - hm.lo[ax]) * hm.inv_h[ax]; /* subvoxel units */
+        if (!std::isfinite(t) || std::fabs(t) > 1e9) {
+          ok = false;
+          break;
+        }
+        const double ft = std::floor(t);
+        int64_t s = (int64_t)ft;
+        const int nn = hm.n[ax];
+        int64_t sw = s % nn;
+        if (sw < 0) sw += nn; /* a periodic image */
+        sv[ax] = (int)sw;
+        int u = (int)((t - ft) * per[ax]);
+        u = std::min(std::max(u, 0), per[ax] - 1);
+        cell[ax] = (lk > 0 && ax < 2) ? std::min(u, ku - 2) : u;
+      }
+      uint32_t rec = 0;
+      if (ok) {
+        const int64_t s = ((int64_t)sv[0] * hm.n[1] + sv[1]) * hm.n[2] + sv[2];
+        if (lk > 0) {
+          const int32_t base = hm.sv_base[(size_t)s];
+          if (base >= 0) {
+            const size_t q = (size_t)base + ((size_t)cell[0] * ku + cell[1]) * k + cell[2];
+            rec = hm.cell_start[q + 1] - hm.cell_start[q];
+          }
+        } else {
+          rec = hm.cell_start[(size_t)s + 1] - hm.cell_start[(size_t)s];
+        }
+      }
+      w[i] = 1.0 + c * (double)std::min<uint32_t>(rec, 40u);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work, n * (int64_t)t / n_thr, n * (int64_t)(t + 1) / n_thr);
+  work(0, n / n_thr);
+  for (auto &t : th) t.join();
+}
+
+/* host only: the weights dsim_partition_by_position uses on this mesh, for a process that cuts the walkers itself
+ * (dsim_partition_walkers): out_cost[i] for the n positions */
+extern "C" int dsim_mesh_walker_cost(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
+                                     const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                                     const int64_t *triangle_indices, int64_t n_refs, double step_l, const double *pos, int64_t n, double *out_cost) {
+  if (!pos || !out_cost || n < 0) return fail(DSIM_ERR_INVALID, "dsim_mesh_walker_cost: bad argument");
+  HostMesh hm;
+  DevMesh none;
+  int rc = upload_mesh(none, nullptr, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, step_l,
+                       nullptr, &hm);
+  if (rc) return rc;
+  mesh_walker_cost(hm, pos, n, out_cost);
+  return DSIM_OK;
+}
+
+/* [r5] Walkers cut into n_parts by SPACE: ordered along the Morton curve of `pos` (21 bits per axis, cubic cells over the
+ * bounding box of the finite coordinates; ties by walker index), part k is the k-th stretch of that order.  weights ==
+ * NULL: the balanced sizes of the contiguous cut (the first n % n_parts parts hold one walker more); else stretches of
+ * equal total weight (every part keeps at least one walker while n >= n_parts).  ids_out (n): the walkers of part 0 in
+ * ascending order, then those of part 1, ...; part_start (n_parts + 1): where each part begins in ids_out.  Host only,
+ * deterministic - every rank of a job computes the same cut from the same positions. */
+extern "C" int dsim_partition_walkers(const double *pos, int64_t n, int32_t n_parts, const double *weights, int64_t *ids_out, int64_t *part_start) {
+  if (!pos || !ids_out || !part_start || n < 0 || n_parts < 1) return fail(DSIM_ERR_INVALID, "dsim_partition_walkers: bad argument");
+  const size_t G = (size_t)n_parts;
+  const int64_t base = n / n_parts, extra = n % n_parts;
   for (size_t k = 0; k <= G; k++) part_start[k] = (int64_t)k * base + std::min<int64_t>((int64_t)k, extra);
   if (n == 0) return DSIM_OK;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -552,7 +638,7 @@ extern "C" int dsim_partition_walkers(const double *pos, int64_t n, int32_t n_sh
   /* ONE scale for the three axes: the cells of the curve are cubes in space (a thin substrate keeps its thin axis' top bits at 0) */
   double ext = 0;
   for (int c = 0; c < 3; c++) ext = std::max(ext, hi[c] - lo[c]);
-  const double scale[3] = {ext > 0 ? 2097151.0 / ext : 0.0, ext > 0 ? 2097151.0 / ext : 0.0, ext > 0 ? 2097151.0 / ext : 0.0};
+  const double scale = ext > 0 ? 2097151.0 / ext : 0.0;
   auto spread = [](uint64_t v) { /* 21 bits -> every third bit */
     v &= 0x1fffffULL;
     v = (v | v << 32) & 0x1f00000000ffffULL;
@@ -568,14 +654,14 @@ extern "C" int dsim_partition_walkers(const double *pos, int64_t n, int32_t n_sh
     bool operator<(const Key &o) const { return key != o.key ? key < o.key : idx < o.idx; }
   };
   std::vector<Key> keys((size_t)n);
+  const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n / 65536));
   {
-    const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n / 65536));
     auto work = [&](int64_t a, int64_t b) {
       for (int64_t i = a; i < b; i++) {
         uint64_t q[3];
         for (int c = 0; c < 3; c++) {
           const double v = pos[3 * i + c];
-          const double t = std::isfinite(v) ? (v - lo[c]) * scale[c] : 0.0;
+          const double t = std::isfinite(v) ? (v - lo[c]) * scale : 0.0;
           q[c] = (uint64_t)std::min(2097151.0, std::max(0.0, t));
         }
         keys[(size_t)i] = Key{spread(q[0]) << 2 | spread(q[1]) << 1 | spread(q[2]), i};
@@ -586,16 +672,45 @@ extern "C" int dsim_partition_walkers(const double *pos, int64_t n, int32_t n_sh
     work(0, n / n_thr);
     for (auto &t : th) t.join();
   }
-  /* only the cut points matter, not the order inside a part: bisect with nth_element, O(n log G) */
-  std::function<void(size_t, size_t)> cut = [&](size_t a, size_t b) { /* parts [a, b) own keys[part_start[a], part_start[b]) */
+  /* bisection with nth_element into chunks [cs[a], cs[b]): O(n log chunks), the halves on threads of their own */
+  std::vector<int64_t> cs;
+  std::function<void(size_t, size_t)> cut = [&](size_t a, size_t b) {
     if (b - a < 2) return;
     const size_t m = (a + b) / 2;
-    std::nth_element(keys.begin() + part_start[a], keys.begin() + part_start[m], keys.begin() + part_start[b]);
+    std::nth_element(keys.begin() + cs[a], keys.begin() + cs[m], keys.begin() + cs[b]);
     std::thread left(cut, a, m);
     cut(m, b);
     left.join();
   };
-  cut(0, G);
+  if (!weights) { /* only the cut points matter, not the order inside a part */
+    cs.assign(part_start, part_start + G + 1);
+    cut(0, G);
+  } else {
+    /* the whole order: 16 chunks by count, each sorted on its own thread; then the running weight along the curve */
+    const size_t P = (size_t)std::max<int64_t>(1, std::min<int64_t>(16, n / 4096));
+    cs.resize(P + 1);
+    for (size_t q = 0; q <= P; q++) cs[q] = n * (int64_t)q / (int64_t)P;
+    cut(0, P);
+    {
+      std::vector<std::thread> th;
+      for (size_t q = 1; q < P; q++) th.emplace_back([&, q]() { std::sort(keys.begin() + cs[q], keys.begin() + cs[q + 1]); });
+      std::sort(keys.begin() + cs[0], keys.begin() + cs[1]);
+      for (auto &t : th) t.join();
+    }
+    long double total = 0;
+    for (int64_t i = 0; i < n; i++) total += (long double)std::max(0.0, weights[i]);
+    long double run = 0;
+    size_t k = 1;
+    for (int64_t j = 0; j < n && k < G; j++) {
+      run += (long double)std::max(0.0, weights[keys[(size_t)j].idx]);
+      while (k < G && run >= total * (long double)k / (long double)G) part_start[k++] = j + 1;
+    }
+    while (k < G) part_start[k++] = n;
+    if (n >= (int64_t)G) { /* nobody stays empty */
+      for (size_t q = 1; q < G; q++) part_start[q] = std::max(part_start[q], part_start[q - 1] + 1);
+      for (size_t q = G - 1; q >= 1; q--) part_start[q] = std::min(part_start[q], part_start[q + 1] - 1);
+    }
+  }
   std::vector<std::thread> th;
   auto finish = [&](size_t k) {
     int64_t *ids = ids_out + part_start[k];
@@ -631,37 +746,59 @@ extern "C" int dsim_set_walker_ids(dsim_handle h, const int64_t *ids) {
 /* [r5] Cut the walkers of a multi-device handle into its shards by SPACE (dsim_partition_walkers) and set their
  * positions.  A mesh shard then works in ITS part of the substrate: at an eighth of the walkers per region a GPU of an
  * 8-GPU job dragged the whole index through its caches (the fill emits positions in (launch, thread) order: a range of
- * indices is a random sample of every dendrite).  Nothing else changes: walker i keeps RNG state i (rng_init_kernel
- * takes the index list) and position i, every host array of the handle stays in walker order (rows are gathered /
- * scattered through the lists), the exact integer signal sums do not depend on the cut.  Call it instead of
- * dsim_set_positions, before the first run; RNG states seeded with dsim_rng_init_device are re-seeded under the new cut,
- * states given with dsim_set_rng_states are moved.  On a single-device handle: dsim_set_positions. */
+ * indices is a random sample of every dendrite).  When the handle knows its mesh (dsim_set_mesh came first) the parts
+ * are of equal estimated COST (mesh_walker_cost), not of equal counts - the walkers of a soma are cheap, those of thin
+ * dendrites dear, and the job ends with its slowest shard: the shards are created again with their new sizes (the
+ * device copies of the index move over).  Nothing else changes: walker i keeps RNG state i (rng_init_kernel takes the
+ * index list) and position i, every host array of the handle stays in walker order (rows are gathered / scattered
+ * through the lists), the exact integer signal sums do not depend on the cut.  Call it instead of dsim_set_positions,
+ * before the first run; RNG states seeded with dsim_rng_init_device are re-seeded under the new cut, states given with
+ * dsim_set_rng_states are moved.  On a single-device handle: dsim_set_positions. */
 extern "C" int dsim_partition_by_position(dsim_handle h, const double *pos) {
   if (!h || !pos) return fail(DSIM_ERR_INVALID, "dsim_partition_by_position: null argument");
   if (!IS_MULTI(h) || h->shards.size() < 2) return dsim_set_positions(h, pos);
   if (h->has_run) return fail(DSIM_ERR_STATE, "dsim_partition_by_position: the handle has already run");
   const int64_t n = h->n;
   const size_t G = h->shards.size();
+  if ((int64_t)G > n) return dsim_set_positions(h, pos);
   std::vector<uint64_t> states;
   if (h->states_given) { /* explicit RNG states: collect them under the old cut */
     states.resize((size_t)n * 2);
     const int rc = dsim_get_rng_states(h, states.data());
     if (rc) return rc;
   }
-  /* the shards were created with the balanced contiguous sizes - exactly the parts of dsim_partition_walkers when no
-   * shard is empty (more devices than walkers leaves shards out: then the sizes differ and the range cut stays) */
-  if ((int64_t)G > n) return dsim_set_positions(h, pos);
+  std::vector<double> weights;
+  if (h->host_mesh && !h->keep_g[0].empty()) {
+    weights.resize((size_t)n);
+    mesh_walker_cost(*h->host_mesh, pos, n, weights.data());
+  }
   std::vector<int64_t> ids((size_t)n), start(G + 1);
-  int rc = dsim_partition_walkers(pos, n, (int32_t)G, ids.data(), start.data());
+  int rc = dsim_partition_walkers(pos, n, (int32_t)G, weights.empty() ? nullptr : weights.data(), ids.data(), start.data());
   if (rc) return rc;
-  for (size_t k = 0; k < G; k++)
-    if (start[k + 1] - start[k] != h->shards[k]->n) return fail(DSIM_ERR_STATE, "dsim_partition_by_position: shard sizes do not match");
+  bool resize = false;
+  for (size_t k = 0; k < G; k++) resize = resize || start[k + 1] - start[k] != h->shards[k]->n;
   h->shard_ids.assign(G, std::vector<int64_t>());
-  rc = multi_each(h, [&](int k, dsim_sim *sh, int64_t) -> int {
+  rc = multi_each(h, [&](int k, dsim_sim *old, int64_t) -> int {
     h->shard_ids[(size_t)k].assign(ids.begin() + start[(size_t)k], ids.begin() + start[(size_t)k + 1]);
+    dsim_sim *sh = old;
+    if (resize) { /* the shard again, with its new number of walkers; the device copy of the index moves over */
+      sh = nullptr;
+      int rc1 = dsim_create(&sh, old->device, start[(size_t)k + 1] - start[(size_t)k], h->first, h->M, h->T, h->keep_g[0].data(), h->keep_g[1].data(),
+                            h->keep_g[2].data(), h->dt, h->step_l);
+      if (rc1) return rc1;
+      sh->mesh = old->mesh;
+      old->mesh = DevMesh();
+      const int *t = h->keep_tune;
+      rc1 = dsim_set_tuning(sh, t[0], t[1], t[2], t[3], t[4], t[5]);
+      if (rc1 == DSIM_OK && h->keep_recording) rc1 = dsim_set_recording(sh, 1);
+      (void)dsim_destroy(old);
+      h->shards[(size_t)k] = sh;
+      if (rc1) return rc1;
+    }
     sh->first = h->first; /* slot i holds walker first + ids[i] */
     return dsim_set_walker_ids(sh, h->shard_ids[(size_t)k].data());
   });
+  for (size_t k = 0; k < G; k++) h->shard_off[k] = start[k];
   if (rc) return rc;
   rc = dsim_set_positions(h, pos);
   if (rc) return rc;
@@ -980,8 +1117,22 @@ extern "C" int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, c
 extern "C" int dsim_set_mesh(dsim_handle h, const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
                              const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                              const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs) {
-  MULTI_FORWARD(h, dsim_set_mesh(s_, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
+  if (IS_MULTI(h)) {
+    /* [r5] the index is built ONCE on the host and handed to every shard, which only allocates and copies on its own
+     * device (round 4: every shard built it - G times the host work, G x 32 threads, G temporary copies) */
+    std::shared_ptr<HostMesh> built(new HostMesh());
+    DevMesh none;
+    int rc = upload_mesh(none, nullptr, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs,
+                         h->step_l, nullptr, built.get());
+    if (rc) return rc;
+    h->host_mesh = built;
+    const HostMesh &hm = *built;
+    return multi_each(h, [&](int, dsim_sim *sh, int64_t) -> int {
+      HIP_TRY(hipSetDevice(sh->device));
+      return upload_mesh_host(sh->mesh, sh->stream, hm);
+    });
+  }
   HIP_TRY(hipSetDevice(h->device));
   return upload_mesh(h->mesh, h->stream, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs,
                      h->step_l);
@@ -1839,6 +1990,7 @@ extern "C" int dsim_debug_timers(unsigned long long *out16) {
 #endif
 
 extern "C" int dsim_set_recording(dsim_handle h, int32_t enable) {
+  if (IS_MULTI(h)) h->keep_recording = enable != 0;
   MULTI_FORWARD(h, dsim_set_recording(s_, enable));
   if (!h) return fail(DSIM_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
@@ -2656,6 +2808,93 @@ extern "C" int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t 
   }
   const std::string keep = g_err;
   dsim_fill_close(fs);
+  g_err = keep;
+  return rc;
+}
+
+/* [r5] dsim_fill_mesh with the threads of every launch split over several devices - one fill session per listed device
+ * (a device may be named more than once), each on a host thread of its own, the per-launch accepted counts merged in
+ * memory: what sharding.fill_mesh_sharded does across processes with an all-gather.  Thread t draws from RNG state t
+ * whatever the split and the accepted candidates of a launch are appended in thread order (simulations.py:573-576), so
+ * the rows are those of dsim_fill_mesh bit for bit; the device work per device is 1 / n_devices of it. */
+extern "C" int dsim_fill_mesh_multi(const int32_t *device_ids, int32_t n_devices, int64_t n_points, int intra, uint64_t seed,
+                                    const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                                    const double voxel_size[3], const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
+                                    const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double *out_points) {
+  if (!device_ids || n_devices < 1 || n_devices > 1024) return fail(DSIM_ERR_INVALID, "dsim_fill_mesh_multi: bad device list");
+  if (n_points <= 0 || !out_points || !voxel_size) return fail(DSIM_ERR_INVALID, "dsim_fill_mesh_multi: bad arguments");
+  const int G = (int)std::min<int64_t>(n_devices, n_points);
+  if (G == 1)
+    return dsim_fill_mesh(device_ids[0], n_points, intra, seed, vertices, n_vertices, faces, n_faces, voxel_size, xs, ys, zs, n_sv,
+                          subvoxel_indices, triangle_indices, n_refs, out_points);
+  std::vector<dsim_fill *> fs((size_t)G, nullptr);
+  std::vector<int64_t> t0((size_t)G + 1);
+  for (int k = 0; k <= G; k++) t0[(size_t)k] = (int64_t)k * (n_points / G) + std::min<int64_t>(k, n_points % G);
+  std::vector<int> rcs((size_t)G, DSIM_OK);
+  std::vector<std::string> msgs((size_t)G);
+  auto each = [&](const std::function<int(int)> &f) -> int {
+    std::vector<std::thread> th;
+    auto work = [&](int k) {
+      rcs[(size_t)k] = f(k);
+      if (rcs[(size_t)k] != DSIM_OK) msgs[(size_t)k] = g_err;
+    };
+    for (int k = 1; k < G; k++) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int k = 0; k < G; k++)
+      if (rcs[(size_t)k] != DSIM_OK) return fail(rcs[(size_t)k], "dsim_fill_mesh_multi: session %d on device %d: %s", k, device_ids[k], msgs[(size_t)k].c_str());
+    return DSIM_OK;
+  };
+  int rc = each([&](int k) {
+    return dsim_fill_open(&fs[(size_t)k], device_ids[k], t0[(size_t)k], t0[(size_t)k + 1], intra, seed, vertices, n_vertices, faces, n_faces, voxel_size,
+                          xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs);
+  });
+  int64_t have = 0, launches = 0, batch = 1;
+  std::vector<std::vector<int64_t>> counts((size_t)G);
+  std::vector<std::vector<double>> pts((size_t)G);
+  std::vector<int64_t> rows((size_t)G, 0);
+  while (rc == DSIM_OK && have < n_points) {
+    rc = each([&](int k) {
+      const int64_t threads = t0[(size_t)k + 1] - t0[(size_t)k];
+      /* a session's accepted points beyond the (n_points - have)-th cannot be needed; with an estimate of the rate the
+       * buffer stays small (8 x the expectation - an overflow is reported below, never dropped silently) */
+      int64_t cap = std::min<int64_t>(n_points - have, threads * batch);
+      if (launches > 0 && have > 0) cap = std::min<int64_t>(cap, (int64_t)(8.0 * (double)have / (double)launches * (double)batch * (double)threads / (double)n_points) + 100000);
+      counts[(size_t)k].assign((size_t)batch, 0);
+      pts[(size_t)k].resize((size_t)std::max<int64_t>(cap, 1) * 3);
+      int rc1 = dsim_fill_run(fs[(size_t)k], batch, counts[(size_t)k].data(), pts[(size_t)k].data(), cap, &rows[(size_t)k]);
+      if (rc1) return rc1;
+      int64_t got = 0;
+      for (int64_t c : counts[(size_t)k]) got += c;
+      if (got > rows[(size_t)k] && rows[(size_t)k] < n_points - have) return fail(DSIM_ERR_STATE, "%lld accepted points in one batch overflow the buffer of %lld", (long long)got, (long long)cap);
+      return DSIM_OK;
+    });
+    if (rc) break;
+    /* launch l of the batch: its accepted candidates in thread order = session 0's, then session 1's, ... */
+    int64_t at = have;
+    std::vector<int64_t> used((size_t)G, 0);
+    for (int64_t l = 0; l < batch; l++)
+      for (int k = 0; k < G; k++) {
+        const int64_t c = counts[(size_t)k][(size_t)l];
+        const int64_t avail = std::max<int64_t>(0, std::min<int64_t>(c, rows[(size_t)k] - used[(size_t)k]));
+        const int64_t take = std::max<int64_t>(0, std::min<int64_t>(avail, n_points - at));
+        if (take > 0) memcpy(out_points + at * 3, pts[(size_t)k].data() + used[(size_t)k] * 3, (size_t)take * 3 * sizeof(double));
+        used[(size_t)k] += c;
+        at += c;
+      }
+    launches += batch;
+    have = at;
+    if (launches > 1000000) rc = fail(DSIM_ERR_STATE, "dsim_fill_mesh: no progress after 1000000 launches (is the surface closed?)");
+    if (have > 0 && have < n_points) { /* the batch rule of dsim_fill_mesh */
+      const double left = (double)(n_points - have) / ((double)have / (double)launches);
+      batch = (int64_t)std::min(64.0, std::max(1.0, std::floor(left * 0.9)));
+    } else if (have == 0) {
+      batch = std::min<int64_t>(batch * 2, 64);
+    }
+  }
+  const std::string keep = g_err;
+  for (dsim_fill *f : fs)
+    if (f) (void)dsim_fill_close(f);
   g_err = keep;
   return rc;
 }

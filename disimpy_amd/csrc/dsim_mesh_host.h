@@ -385,10 +385,30 @@ struct HostFineGrid {
   float qs = 0;
 };
 
+/* everything dsim_set_mesh puts on a device, as built on the host: built ONCE per call and uploaded to every shard of a
+ * multi-device handle (round 4 had every shard build its own: G times the host work, G x 32 threads, G temporary copies) */
+struct HostMesh {
+  std::vector<double> rec;
+  std::vector<int2> ranges;
+  std::vector<int32_t> refs, sv_base, cidx;
+  std::vector<uint32_t> cell_start, recs_before, cbits;
+  std::vector<uint4> packed;
+  std::vector<double> bounds;
+  int lk = 0, clear_lf = 0;
+  double clear_frac = 0, step_l = 0;
+  float qs = 0;
+  int64_t n_sub = 0;
+  int n[3] = {0, 0, 0};
+  double inv_h[3] = {0, 0, 0}, inv_l[3] = {0, 0, 0}, lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  bool coop_ok = false;
+};
+
+static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm);
+
 static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
                        int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                        const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l,
-                       HostFineGrid *host_only = nullptr) {
+                       HostFineGrid *host_only = nullptr, HostMesh *build_only = nullptr) {
   if (!vertices || !faces || !xs || !ys || !zs || !n_sv || !subvoxel_indices || (!triangle_indices && n_refs))
     return fail(DSIM_ERR_INVALID, "mesh: null argument");
   if (n_faces <= 0 || n_vertices <= 0 || n_faces > INT32_MAX || n_refs > INT32_MAX || n_refs < 0)
@@ -397,9 +417,13 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     if (n_sv[k] < 1 || n_sv[k] > 4096) return fail(DSIM_ERR_INVALID, "mesh: n_sv[%d] = %lld out of range", k, (long long)n_sv[k]);
   const int64_t n_sub = n_sv[0] * n_sv[1] * n_sv[2];
   if (n_sub > INT32_MAX) return fail(DSIM_ERR_INVALID, "mesh: too many subvoxels");
-  if (!host_only) free_mesh(dm);
+  if (!host_only && !build_only) free_mesh(dm);
+  HostMesh local_hm;
+  HostMesh &hm = build_only ? *build_only : local_hm;
+  hm = HostMesh();
   /* pre-gathered triangle records {A, B - A, C - A} (simulations.py:259-262 does these subtractions per candidate) */
-  std::vector<double> rec((size_t)n_faces * DS_TRI_STRIDE);
+  std::vector<double> &rec = hm.rec;
+  rec.assign((size_t)n_faces * DS_TRI_STRIDE, 0.0);
   for (int64_t f = 0; f < n_faces; f++) {
     int64_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
     if (ia < 0 || ib < 0 || ic < 0 || ia >= n_vertices || ib >= n_vertices || ic >= n_vertices)
@@ -425,14 +449,16 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       rec[f * DS_TRI_STRIDE + 11] = nz;
     }
   }
-  std::vector<int2> ranges((size_t)n_sub);
+  std::vector<int2> &ranges = hm.ranges;
+  ranges.assign((size_t)n_sub, make_int2(0, 0));
   for (int64_t s = 0; s < n_sub; s++) {
     int64_t a = subvoxel_indices[s * 2], b = subvoxel_indices[s * 2 + 1];
     if (a < 0 || b < a || b > n_refs) return fail(DSIM_ERR_INVALID, "mesh: subvoxel %lld has a bad range", (long long)s);
     ranges[s] = make_int2((int)a, (int)b);
   }
 
-  std::vector<int32_t> refs((size_t)std::max<int64_t>(n_refs, 1));
+  std::vector<int32_t> &refs = hm.refs;
+  refs.assign((size_t)std::max<int64_t>(n_refs, 1), 0);
   for (int64_t i = 0; i < n_refs; i++) {
     if (triangle_indices[i] < 0 || triangle_indices[i] >= n_faces) return fail(DSIM_ERR_INVALID, "mesh: triangle index out of range");
     refs[i] = (int32_t)triangle_indices[i];
@@ -504,10 +530,12 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   /* units, cell span and cell slots per axis */
   const int nun[3] = {lk > 0 ? 2 * k : 1, lk > 0 ? 2 * k : 1, k}, span[3] = {lk > 0 ? 2 : 1, lk > 0 ? 2 : 1, 1};
   const size_t slots = (size_t)nun[0] * nun[1] * nun[2];
-  std::vector<int32_t> sv_base((size_t)(lk > 0 ? n_sub : 1), -1);
-  std::vector<uint32_t> cell_start;
+  std::vector<int32_t> &sv_base = hm.sv_base;
+  sv_base.assign((size_t)(lk > 0 ? n_sub : 1), -1);
+  std::vector<uint32_t> &cell_start = hm.cell_start;
   std::vector<HostRecord> mrec;
-  std::vector<uint32_t> recs_before((size_t)(lk > 0 ? n_sub + 1 : 1), 0u); /* records of the subvoxels before s (dense table) */
+  std::vector<uint32_t> &recs_before = hm.recs_before;
+  recs_before.assign((size_t)(lk > 0 ? n_sub + 1 : 1), 0u); /* records of the subvoxels before s (dense table) */
   cell_start.reserve((size_t)(lk > 0 ? n_nonempty * slots : n_sub) + 1);
   {
     /* per non-empty subvoxel: the record count of every slot and the records, built by a few host threads (the subvoxels are
@@ -637,7 +665,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     const double *b3[3] = {xs, ys, zs};
     qs = record_quantum(b3, n_sv);
   }
-  std::vector<uint4> packed;
+  std::vector<uint4> &packed = hm.packed;
   pack_records(mrec, qs, packed);
   if (host_only) { /* no device involved */
     host_only->lk = lk;
@@ -648,47 +676,73 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     host_only->qs = qs;
     return DSIM_OK;
   }
-  std::vector<double> bounds;
+  std::vector<double> &bounds = hm.bounds;
   bounds.insert(bounds.end(), xs, xs + n_sv[0] + 1);
   bounds.insert(bounds.end(), ys, ys + n_sv[1] + 1);
   bounds.insert(bounds.end(), zs, zs + n_sv[2] + 1);
+  hm.step_l = step_l;
+  hm.lk = lk;
+  hm.qs = qs;
+  hm.n_sub = n_sub;
   if (step_l > 0) { /* the walk's clearance map (not used by the fill kernel, which passes step_l = 0) */
-    std::vector<int32_t> cidx;
-    std::vector<uint32_t> cbits;
     const double *bb[3] = {xs, ys, zs};
-    build_clearance_map(vertices, faces, n_faces, bb, n_sv, step_l, cidx, cbits, dm.clear_lf, dm.clear_frac);
-    if (!cidx.empty()) {
-      HIP_TRY(hipMalloc(&dm.clear_idx, cidx.size() * sizeof(int32_t)));
-      HIP_TRY(hipMalloc(&dm.clear_bits, cbits.size() * sizeof(uint32_t)));
-      HIP_TRY(hipMemcpyAsync(dm.clear_idx, cidx.data(), cidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipMemcpyAsync(dm.clear_bits, cbits.data(), cbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipStreamSynchronize(stream)); /* the host vectors die with this scope */
-    }
+    build_clearance_map(vertices, faces, n_faces, bb, n_sv, step_l, hm.cidx, hm.cbits, hm.clear_lf, hm.clear_frac);
   }
-  HIP_TRY(hipMalloc(&dm.tri, rec.size() * sizeof(double)));
-  HIP_TRY(hipMalloc(&dm.sv_range, ranges.size() * sizeof(int2)));
-  HIP_TRY(hipMalloc(&dm.tri_idx, refs.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&dm.mrec, packed.size() * sizeof(uint4)));
-  HIP_TRY(hipMalloc(&dm.sv_base, sv_base.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&dm.cell_start, cell_start.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpyAsync(dm.mrec, packed.data(), packed.size() * sizeof(uint4), hipMemcpyHostToDevice, stream));
-  dm.qs = qs;
-  HIP_TRY(hipMemcpyAsync(dm.sv_base, sv_base.data(), sv_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  dm.lk = lk;
-  if (lk > 0 && step_l > 0) { /* (the fill session passes step_l = 0: it never walks the fine grid)
+  const double *b3[3] = {xs, ys, zs};
+  for (int k = 0; k < 3; k++) {
+    double L = b3[k][n_sv[k]] - b3[k][0];
+    hm.n[k] = (int)n_sv[k];
+    hm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
+    hm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
+    hm.lo[k] = b3[k][0];
+    hm.hi[k] = b3[k][n_sv[k]];
+  }
+  hm.coop_ok = true;
+  for (int k = 0; k < 3; k++) {
+    const double L = b3[k][n_sv[k]] - b3[k][0], h = L / (double)n_sv[k];
+    if (!(L > 0) || !std::isfinite(L) || b3[k][0] != 0.0) hm.coop_ok = false;
+    for (int64_t i = 0; i <= n_sv[k] && hm.coop_ok; i++)
+      if (!(std::fabs(b3[k][i] - (double)i * h) <= 1e-6 * h)) hm.coop_ok = false;
+  }
+  if (build_only) return DSIM_OK;
+  return upload_mesh_host(dm, stream, hm);
+}
+
+/* the host arrays of one mesh onto one device (the current device is the caller's business) */
+static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm) {
+  free_mesh(dm);
+  dm.clear_lf = hm.clear_lf;
+  dm.clear_frac = hm.clear_frac;
+  if (!hm.cidx.empty()) {
+    HIP_TRY(hipMalloc(&dm.clear_idx, hm.cidx.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&dm.clear_bits, hm.cbits.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(dm.clear_idx, hm.cidx.data(), hm.cidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dm.clear_bits, hm.cbits.data(), hm.cbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  }
+  HIP_TRY(hipMalloc(&dm.tri, hm.rec.size() * sizeof(double)));
+  HIP_TRY(hipMalloc(&dm.sv_range, hm.ranges.size() * sizeof(int2)));
+  HIP_TRY(hipMalloc(&dm.tri_idx, hm.refs.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&dm.mrec, hm.packed.size() * sizeof(uint4)));
+  HIP_TRY(hipMalloc(&dm.sv_base, hm.sv_base.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&dm.cell_start, hm.cell_start.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpyAsync(dm.mrec, hm.packed.data(), hm.packed.size() * sizeof(uint4), hipMemcpyHostToDevice, stream));
+  dm.qs = hm.qs;
+  HIP_TRY(hipMemcpyAsync(dm.sv_base, hm.sv_base.data(), hm.sv_base.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.cell_start, hm.cell_start.data(), hm.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  dm.lk = hm.lk;
+  if (hm.lk > 0 && hm.step_l > 0) { /* (the fill session passes step_l = 0: it never walks the fine grid)
      * [r5] the cooperative traversal's one-level table: a slot block for EVERY subvoxel (C5b: 125 000 subvoxels x 2 048
      * slots x 4 bytes = 1 GB of which the 2 280 non-empty blocks are ever read; 288 GB of HBM per GPU afford it), expanded
      * on the device from the compact arrays.  DSIM_DENSE_CELLS_MB caps it (default 4096, 0 = never: two-level look-ups) */
-    const int lcs = 3 * lk + 2;
-    const uint64_t n_slots = (uint64_t)n_sub << lcs;
+    const int lcs = 3 * hm.lk + 2;
+    const uint64_t n_slots = (uint64_t)hm.n_sub << lcs;
     double cap_mb = 4096;
     if (const char *e = getenv("DSIM_DENSE_CELLS_MB")) cap_mb = atof(e);
     if ((double)(n_slots + 1) * 4.0 <= cap_mb * 1048576.0) {
       uint32_t *before_d = nullptr;
       HIP_TRY(hipMalloc(&dm.cell_dense, (size_t)(n_slots + 1) * sizeof(uint32_t)));
-      HIP_TRY(hipMalloc(&before_d, recs_before.size() * sizeof(uint32_t)));
-      hipError_t e = hipMemcpyAsync(before_d, recs_before.data(), recs_before.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+      HIP_TRY(hipMalloc(&before_d, hm.recs_before.size() * sizeof(uint32_t)));
+      hipError_t e = hipMemcpyAsync(before_d, hm.recs_before.data(), hm.recs_before.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
       if (e == hipSuccess) {
         expand_cells_kernel<<<(unsigned)((n_slots + 256) / 256), 256, 0, stream>>>(dm.sv_base, dm.cell_start, before_d, lcs, n_slots, dm.cell_dense);
         e = hipGetLastError();
@@ -698,31 +752,18 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       if (e != hipSuccess) return fail(DSIM_ERR_HIP, "dense cell table: %s", hipGetErrorString(e));
     }
   }
-  HIP_TRY(hipMalloc(&dm.bounds, bounds.size() * sizeof(double)));
-  HIP_TRY(hipMemcpyAsync(dm.tri, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.sv_range, ranges.data(), ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.tri_idx, refs.data(), refs.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(dm.bounds, bounds.data(), bounds.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMalloc(&dm.bounds, hm.bounds.size() * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(dm.tri, hm.rec.data(), hm.rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.sv_range, hm.ranges.data(), hm.ranges.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.tri_idx, hm.refs.data(), hm.refs.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(dm.bounds, hm.bounds.data(), hm.bounds.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  dm.nx = (int)n_sv[0];
-  dm.ny = (int)n_sv[1];
-  dm.nz = (int)n_sv[2];
-  const double *b3[3] = {xs, ys, zs};
-  for (int k = 0; k < 3; k++) {
-    double L = b3[k][n_sv[k]] - b3[k][0];
-    dm.inv_h[k] = L > 0 ? (double)n_sv[k] / L : 0.0;
-    dm.inv_l[k] = L > 0 ? 1.0 / L : 0.0;
-    dm.lo[k] = b3[k][0];
-    dm.hi[k] = b3[k][n_sv[k]];
-  }
+  dm.nx = hm.n[0];
+  dm.ny = hm.n[1];
+  dm.nz = hm.n[2];
+  for (int k = 0; k < 3; k++) dm.inv_h[k] = hm.inv_h[k], dm.inv_l[k] = hm.inv_l[k], dm.lo[k] = hm.lo[k], dm.hi[k] = hm.hi[k];
   dm.set = true;
-  dm.coop_ok = true;
-  for (int k = 0; k < 3; k++) {
-    const double L = b3[k][n_sv[k]] - b3[k][0], h = L / (double)n_sv[k];
-    if (!(L > 0) || !std::isfinite(L) || b3[k][0] != 0.0) dm.coop_ok = false;
-    for (int64_t i = 0; i <= n_sv[k] && dm.coop_ok; i++)
-      if (!(std::fabs(b3[k][i] - (double)i * h) <= 1e-6 * h)) dm.coop_ok = false;
-  }
+  dm.coop_ok = hm.coop_ok;
   return DSIM_OK;
 }
 

@@ -182,7 +182,7 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
     about walkers that exceeded ``max_iter`` with GLOBAL walker indices (disimpy/simulations.py:1406-1429).  ``traj``:
     rank 0 writes the reference's trajectories file (:1043-1048, :1194, :1211-1213), the ranks' columns gathered per range
     of steps.  On a mesh the ranks cut the walkers by SPACE (include/dsim.h, dsim_partition_walkers: the Morton order of
-    the initial positions in equal parts; every rank computes the same cut), elsewhere by index; walker i keeps RNG
+    the initial positions in parts of equal estimated cost; every rank computes the same cut), elsewhere by index; walker i keeps RNG
     state i and position i either way and the outputs are the single-process bytes.
     (Inside one process ``simulations.simulation`` itself spreads the walkers over all visible GPUs; this entry is
     for jobs that are launched as one process per GPU.)"""
@@ -201,7 +201,9 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
     if world > 1 and substrate.type == "mesh":
         # every rank needs all initial positions for the cut; the shared fill ends in an all-gather of the rows anyway
         positions_all, _ = simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (0, n_walkers), dist=dist)
-        ids_all = _lib.partition_walkers(positions_all, world)
+        cost = _lib.mesh_walker_cost(substrate.vertices, substrate.faces, substrate.xs, substrate.ys, substrate.zs, substrate.n_sv,
+                                     substrate.subvoxel_indices, substrate.triangle_indices, float(np.sqrt(6 * diffusivity * dt)), positions_all)
+        ids_all = _lib.partition_walkers(positions_all, world, cost)  # parts of equal estimated cost
         kw = {"walker_ids": ids_all[rank], "positions_all": positions_all}
         a, b = 0, len(ids_all[rank])
     lines = {"first": True}

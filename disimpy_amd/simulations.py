@@ -106,11 +106,12 @@ def _strip_wall_triangles(substrate):
     return vertices, faces, np.delete(tri, deleted), svi
 
 
-def _fill_mesh(n_points, substrate, intra, seed, cuda_bs=128, device=0, dist=None, walker_range=None):
+def _fill_mesh(n_points, substrate, intra, seed, cuda_bs=128, device=0, dist=None, walker_range=None, devices=None):
     """Sample points uniformly inside (``intra``) or outside the closed surface of
     a triangular mesh on the GPU (disimpy/simulations.py:505-579).  With an initialised
     process group ``dist`` the launches' threads are split over the ranks
-    (sharding.fill_mesh_sharded) and only the rows ``walker_range`` come back."""
+    (sharding.fill_mesh_sharded) and only the rows ``walker_range`` come back; ``devices``: the in-process twin - one
+    fill session per listed device on host threads (dsim_fill_mesh_multi).  The rows are the same either way."""
     if substrate.periodic:
         vertices, faces = substrate.vertices, substrate.faces
         tri, svi = substrate.triangle_indices, substrate.subvoxel_indices
@@ -126,7 +127,7 @@ def _fill_mesh(n_points, substrate, intra, seed, cuda_bs=128, device=0, dist=Non
         return sharding.fill_mesh_sharded(n_points, open_session, dist, device, walker_range)
     return _lib.fill_mesh(
         n_points, intra, seed, vertices, faces, substrate.voxel_size, substrate.xs, substrate.ys, substrate.zs,
-        substrate.n_sv, svi, tri, device=device,
+        substrate.n_sv, svi, tri, device=device, devices=devices,
     )  # fmt: skip
 
 
@@ -252,9 +253,9 @@ def _initial_positions(n_walkers, substrate, seed, quiet, device, walker_range=N
             # the device fill is shared by the ranks (threads of every launch split, sharding.fill_mesh_sharded)
             pos = _fill_mesh(n_walkers, substrate, substrate.init_pos == "intra", seed, device=device, dist=dist, walker_range=(a, b))
         elif substrate.init_pos == "intra":
-            pos = _fill_mesh(n_walkers, substrate, True, seed, device=device)[a:b]
+            pos = _fill_mesh(n_walkers, substrate, True, seed, device=device, devices=devices)[a:b]
         else:
-            pos = _fill_mesh(n_walkers, substrate, False, seed, device=device)[a:b]
+            pos = _fill_mesh(n_walkers, substrate, False, seed, device=device, devices=devices)[a:b]
         if not quiet:
             print("Finished calculating initial positions")
         return pos, None
@@ -331,17 +332,17 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
         if walker_ids is not None:
             sim.set_walker_ids(walker_ids)
         sim.rng_init_device(seed)
+        if substrate.type == "mesh":  # before the positions: a multi-device handle cuts its walkers by the cost the index implies
+            sim.set_mesh(substrate.vertices, substrate.faces, substrate.xs, substrate.ys, substrate.zs,
+                         substrate.n_sv, substrate.subvoxel_indices, substrate.triangle_indices)
         if positions is not None:
             pos = np.ascontiguousarray(positions, dtype=np.float64)
             if substrate.type == "mesh":
                 # several devices: every shard gets a REGION of the substrate (the Morton order of the initial positions
-                # cut into equal counts), not a range of walker indices - the outputs are the same bytes either way
+                # cut into parts of equal estimated cost), not a range of walker indices - the outputs are the same bytes
                 sim.partition_by_position(pos)
             else:
                 sim.set_positions(pos)
-        if substrate.type == "mesh":
-            sim.set_mesh(substrate.vertices, substrate.faces, substrate.xs, substrate.ys, substrate.zs,
-                         substrate.n_sv, substrate.subvoxel_indices, substrate.triangle_indices)
         if traj and traj_sink is None:
             _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions))
         if traj:

@@ -122,18 +122,30 @@ int dsim_set_positions(dsim_handle h, const double *positions_aos);
 
 /* [r5] dsim_set_positions that also cuts the walkers of a multi-device handle (dsim_create_multi) into its shards by
  * SPACE: the walkers are ordered along the Morton curve of the positions and shard k takes the k-th stretch of that
- * order (as many walkers as it had), so that every GPU works in its own part of a mesh substrate instead of at 1/G
- * of the walker density all over it.  The reference has no counterpart (simulations.py:1051 is one GPU).  Walker i
- * keeps RNG state i and position i, host arrays stay in walker order, the exact signal sums do not depend on the cut:
- * every output is the bytes of the contiguous cut.  Before the first dsim_run_* call only; RNG states seeded or given
- * earlier are re-seeded / moved.  Single-device handle: the same as dsim_set_positions. */
+ * order, so that every GPU works in its own part of a mesh substrate instead of at 1/G of the walker density all over
+ * it.  When dsim_set_mesh was called BEFORE, the stretches are of equal estimated cost, not of equal counts (a
+ * walker's cost: 1 + 0.07 x the records of the fine cell it starts in - walkers inside a soma are cheap, those in thin
+ * dendrites dear, and the job ends with its slowest shard); the shards are then created again with their new sizes.
+ * The reference has no counterpart (simulations.py:1051 is one GPU).  Walker i keeps RNG state i and position i,
+ * host arrays stay in walker order, the exact signal sums do not depend on the cut: every output is the bytes of the
+ * contiguous cut.  Before the first dsim_run_* call only; RNG states seeded or given earlier are re-seeded / moved.
+ * Single-device handle: the same as dsim_set_positions. */
 int dsim_partition_by_position(dsim_handle h, const double *positions_aos);
 
-/* The cut itself, host only: the walkers ordered along the Morton curve of their positions (21 bits per axis over the
- * bounding box of the finite coordinates, ties by index), part k = the k-th stretch of that order with the balanced sizes
- * of the contiguous cut.  ids_out (n): the walkers of part 0 ascending, then part 1, ...; part_start (n_parts + 1).
- * Deterministic: every process of a job launched as one process per GPU computes the same cut. */
-int dsim_partition_walkers(const double *positions_aos, int64_t n_walkers, int32_t n_parts, int64_t *ids_out, int64_t *part_start);
+/* The cut itself, host only: the walkers ordered along the Morton curve of their positions (21 bits per axis, cubic
+ * cells over the bounding box of the finite coordinates, ties by index), part k = the k-th stretch of that order -
+ * with the balanced sizes of the contiguous cut (weights == NULL) or of equal total weight.  ids_out (n): the walkers
+ * of part 0 ascending, then part 1, ...; part_start (n_parts + 1).  Deterministic: every process of a job launched as
+ * one process per GPU computes the same cut. */
+int dsim_partition_walkers(const double *positions_aos, int64_t n_walkers, int32_t n_parts, const double *weights, int64_t *ids_out,
+                           int64_t *part_start);
+
+/* The weights dsim_partition_by_position uses on a mesh (host only; the arguments of dsim_set_mesh plus the step
+ * length the handle was created with): out_cost[i] = 1 + 0.07 x min(40, records of the fine cell of positions[i]). */
+int dsim_mesh_walker_cost(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
+                          const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
+                          const int64_t *triangle_indices, int64_t n_refs, double step_l, const double *positions_aos,
+                          int64_t n_walkers, double *out_cost);
 
 /* Single-device handle that holds such a part: slot i is walker first_walker + ids[i] (ascending, n of the handle;
  * NULL: the range again).  dsim_rng_init_device seeds slot i with the state of ITS walker; every other entry point
@@ -208,6 +220,16 @@ int dsim_fill_mesh(int device, int64_t n_points, int intra, uint64_t seed, const
                    const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                    const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs,
                    double *out_points);
+
+/* [r5] The same fill with the threads of every launch split over several devices (one fill session per listed device,
+ * host threads, the per-launch counts merged in memory): the rows of dsim_fill_mesh bit for bit, 1 / n_devices of the
+ * device work each - what simulation() uses on a node with several GPUs (the reference's fill, simulations.py:505-579,
+ * runs on its one GPU). */
+int dsim_fill_mesh_multi(const int32_t *device_ids, int32_t n_devices, int64_t n_points, int intra, uint64_t seed,
+                         const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces,
+                         const double voxel_size[3], const double *xs, const double *ys, const double *zs,
+                         const int64_t n_sv[3], const int64_t *subvoxel_indices, const int64_t *triangle_indices,
+                         int64_t n_refs, double *out_points);
 
 /* The same loop for a RANGE of its threads, so that the GPUs of a node share it (disimpy_amd/sharding.py,
  * fill_mesh_sharded).  Thread t draws one candidate per launch from RNG state t whatever the range, and the reference

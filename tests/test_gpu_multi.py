@@ -95,6 +95,21 @@ def test_mesh_run_cut_by_space_writes_the_same_trajectories_file(mods, tmp_path)
     assert len(out[0][0].splitlines()) == 51 and out[0] == out[1]
 
 
+def test_mesh_fill_split_over_devices_returns_the_same_rows(mods):
+    """dsim_fill_mesh_multi: one fill session per listed device on host threads, per-launch counts merged in memory -
+    the rows of the one-device fill bit for bit (disimpy/simulations.py:505-579), inside and outside the surface"""
+    _lib, gradients, simulations, substrates = mods
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="intra", n_sv=np.array([6, 6, 6]), quiet=True)
+    n = golden("neuron_mesh.npz")
+    neuron = substrates.mesh(n["vertices"], n["faces"].astype(np.int64), True, init_pos="intra", quiet=True)
+    for substrate, count, intra in ((sub, 20011, True), (sub, 5003, False), (neuron, 2000, True)):
+        one = simulations._fill_mesh(count, substrate, intra, 123)
+        for devices in ([0, 0], [0, 0, 0, 0, 0]):
+            many = simulations._fill_mesh(count, substrate, intra, 123, devices=devices)
+            assert one.tobytes() == many.tobytes(), (count, intra, devices)
+
+
 def test_multi_device_handle_state_round_trips(mods):
     """the handle's host arrays cover all walkers in order: every shard reads / fills its slice (ragged split, more
     shards than walkers)"""

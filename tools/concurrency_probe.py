@@ -33,7 +33,7 @@ def main():
         edges = [n * k // S for k in range(S + 1)]
         sims = []
         for k in range(S):
-            sim, _, _ = bench.setup_sim(args, w, n, edges[k], edges[k + 1], 0)
+            sim, _, _, _ = bench.setup_sim(args, w, n, edges[k], edges[k + 1], 0)
             sims.append(sim)
 
         def one_pass(sim):

@@ -13,6 +13,24 @@ run_one() {
     tests) timeout -k 10 1800 python -m pytest tests -m gpu -q -x "$@" 2>&1 | grep -v "$FILTER" | tail -25 | tee gpurun_out/r05/pytest_last.txt ;;
     ab) bash tools/gpu_ab.sh "$@" | tee -a gpurun_out/r05/ab_log.txt ;;
     sh) "$@" ;;
+    # bench lines of the three multi-device paths on the one GPU: default, in-process handle over 0,0, two gloo ranks
+    benches)
+      O=gpurun_out/r05; tag=${1:-x}
+      timeout -k 10 900 python bench.py > $O/bench_default_$tag.json 2> $O/bench_default_$tag.err; echo "default rc=$?"
+      DSIM_DEVICES=0,0 timeout -k 10 600 python bench.py --gpus 2 --mode inprocess --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_inprocess2_$tag.json 2> $O/bench_inprocess2_$tag.err; echo "inprocess rc=$?"
+      timeout -k 10 600 python bench.py --gpus 2 --backend gloo --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_gloo2_$tag.json 2> $O/bench_gloo2_$tag.err; echo "gloo rc=$?"
+      python - <<PY
+import json
+for n in ("default","inprocess2","gloo2"):
+    try:
+        d=json.loads(open("$O/bench_%s_$tag.json"%n).read().strip().splitlines()[-1])
+        s=d.get("signal_rel_err",{}).get("sample_of_timed_run",{})
+        print(n, "value %.4g"%d["value"], "walk %.4g"%d["walk_kernel_spin_steps_per_s"], "setup", {k: round(v,2) for k,v in d["setup_s"].items()}, "sample", s.get("result") if isinstance(s,dict) else s, "e2e", d.get("end_to_end_s"))
+        if "secondary" in d: print("  secondary", {k:(round(v["value"]/1e10,3), v.get("walkers")) for k,v in d["secondary"].items()})
+    except Exception as e:
+        print(n, "FAILED", e); print(open("$O/bench_%s_$tag.err"%n).read()[-1500:])
+PY
+      ;;
     pcs)
       tag=$1; lib=$2; wl=$3; n=$4; method=${5:-stochastic}
       O=/tmp/pcs_$tag; rm -rf $O
