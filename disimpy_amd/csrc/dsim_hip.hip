@@ -1339,7 +1339,6 @@ struct WalkGroup {
   int launch_no = 0;                      /* launch k uses counter set k & 1 */
   double *traj = nullptr;                 /* recorded mode: this group's rows[slot][step][x y z 0] of the handle's buffer */
   int32_t t_pos = 0;                      /* recorded mode: the time step the group has reached */
-  int32_t t_sorted = 0;                   /* recorded mode: the time step of the group's last re-sort */
   double clear_frac = -1;                 /* share of walkers in clear cells as of the last launch's sort (-1: unknown) */
   long long unfinished = 0, steps_left = 0, max_left = 0;
   double passes_per_step = 1.45; /* running estimate: passes a wavefront spends per time step of its walkers */
@@ -1357,7 +1356,7 @@ struct WalkGroup {
  * 28 / 32 / 40 / 48 / 64 KB asked for give 1.025-1.037 / 1.025 / 1.077 / 1.081 / 1.065 / 1.001 / 1.05e10).
  * walk_lds: dynamic LDS of one walk workgroup.  DSIM_PHASE_LDS (bytes) overrides it in tuning runs. */
 static size_t phase_lds_reserve(size_t walk_lds) {
-  if (const char *e = getenv("DSIM_PHASE_LDS")) return (size_t)atol(e);
+  if (const char *e = getenv("DSIM_PHASE_LDS")) return (size_t)std::min<long>(std::max<long>(atol(e), 0L), 64L * 1024L); /* a launch cannot ask for more */
   const size_t cu = 160 * 1024, granule = 1280;
   const size_t per_wg = std::max<size_t>((walk_lds + granule - 1) / granule * granule, granule);
   const size_t max_wg = std::min<size_t>(4, cu / per_wg); /* 4 waves per SIMD: at most four workgroups of 256 */
@@ -1415,7 +1414,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
     }
     g.permuted = presorted; /* orig[] already holds the walkers' original indices */
     g.traj = recorded ? h->traj + (size_t)h->traj_steps * 4 * g.off : nullptr; /* walker-major rows of 32 bytes per step */
-    g.t_pos = g.t_sorted = t_begin;
+    g.t_pos = t_begin;
     g.unfinished = g.v.n;
     g.steps_left = (long long)g.v.n * (t_end - t_begin);
     g.max_left = t_end - t_begin;
@@ -1445,7 +1444,6 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
         int rc = resort_walkers(v, !g.permuted, false, 0, false, (int)(&g - grp));
         if (rc) return rc;
         g.permuted = true;
-        g.t_sorted = ta;
       }
       WalkParams q = p;
       const int c = v->cur;
@@ -1773,7 +1771,10 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
        * walkers 1.47 / 1.53 / 1.53 / 1.50 / 1.43e10 for 1024 / 512 / 256 / 128 / 64 steps, at 1.25e6 walkers
        * 1.285 / 1.32 / 1.34 / 1.33 / 1.27e10 for 512 / 256 / 128 / 64 / 32, C4 at 1e6 walkers 1.13 / 1.15 / 1.175e10 for
        * 512 / 256 / 128 (profiles/history/r04_sweeps_resort_interval.txt) */
-      if (coop4) resort = std::min(resort, rounds < 6.0 ? 128 : 256);
+      /* [r5] with 32-byte records in items of five a launch costs less per step and the sorts weigh more: 1e7 walkers
+       * 1.679 / 1.733 / 1.742 / 1.748e10 for 128 / 256 / 384 / 512 steps, 1.25e6 walkers 1.616 / 1.645 / 1.642 / 1.639e10 for
+       * 64 / 128 / 192 / 256 (profiles/history/r05_sweeps_resort_interval.txt) */
+      if (coop4) resort = std::min(resort, rounds < 6.0 ? 128 : (rounds < 15.0 ? 256 : 512));
     }
     int rc = ensure_sort_buffers(h);
     if (rc) return rc;
@@ -2267,16 +2268,16 @@ extern "C" int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches) 
 }
 
 extern "C" int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches) {
-  if (IS_MULTI(h)) {
-    double sum = 0;
+  if (IS_MULTI(h)) { /* the shards run concurrently: the slowest one's time (like dsim_last_run_ms), everybody's launches */
+    double worst = 0;
     int launches = 0;
     for (dsim_sim *sh : h->shards) {
       double q = 0;
       int32_t nl = 0;
       (void)dsim_last_walk_ms(sh, &q, &nl);
-      sum += q, launches += nl;
+      worst = std::max(worst, q), launches += nl;
     }
-    if (ms) *ms = sum;
+    if (ms) *ms = worst;
     if (n_launches) *n_launches = launches;
     return DSIM_OK;
   }

@@ -37,7 +37,7 @@
  *     abandoned like in the reference (simulations.py:478-479);
  *   - gradient: M >= 1, T >= 1, T * M * 32 bytes of device memory for the re-laid-out waveform.
  *
- * Environment.  The library reads six variables, all of them tuning or diagnostic switches for measurement runs -
+ * Environment.  The library reads eight variables, all of them tuning or diagnostic switches for measurement runs -
  * results never depend on them (the GPU parity tests run with and without):
  *   DSIM_GROUPS=1..4      walker groups (streams) of a mesh run with per-walker clocks; default 2 from 2^18 walkers;
  *   DSIM_SORT_BITS=6..24  log2 of the Morton bins of the walker re-sort; default 18;
@@ -49,7 +49,10 @@
  *                         retired; default: a rule on the walk kernel's own LDS (phase_lds_reserve);
  *   DSIM_FILL_STATS=1     prints the shape of the mesh fill's bucket index on stderr when a fill session opens.
  * The Python binding adds DSIM_LIB=<path> (disimpy_amd/_lib.py): load another build of this library, e.g. an older
- * kernel for a same-box A/B; every symbol of this header must be there, or loading fails.
+ * kernel for a same-box A/B; every symbol of this header must be there, or loading fails - unless DSIM_LIB_OLD_ABI=1
+ * says that the build is an OLDER one kept for such a comparison: entry points it lacks raise when they are called.
+ * Two more switches belong to this round: DSIM_DENSE_CELLS_MB (cap of the one-level cell table of a mesh, default 4096;
+ * 0 = two-level look-ups) and DSIM_COST_PER_RECORD (weight of the spatial cut's cost model, default 0.07).
  */
 #ifndef DSIM_H
 #define DSIM_H
@@ -307,7 +310,7 @@ int dsim_last_run_ms(dsim_handle h, double *ms, int32_t *n_launches);
  * roofline of the dominant kernel is computed from this figure. */
 int dsim_last_walk_ms(dsim_handle h, double *ms, int32_t *n_launches);
 
-/* Mesh runs with M <= 2 (the kernel with per-walker clocks) and at least 2^18 walkers sort and launch the two halves of the shard independently on
+/* Mesh runs with M <= 4 (the kernel with per-walker clocks) and at least 2^18 walkers sort and launch the two halves of the shard independently on
  * two streams, so that one half's launch fills the wavefront slots the other half leaves idle at the end of its
  * launch and during its re-sort (csrc/dsim_hip.hip, run_own_clock).  The launches of the two halves then overlap
  * and the sum above counts the overlap twice: *ms is the time during which at least one walk kernel was running
@@ -338,8 +341,7 @@ int dsim_write_traj_line(const char *path, const double *positions_aos, int64_t 
 /* Tuning knobs (0 keeps the default): threads per workgroup, time steps per
  * LDS gradient tile, measurements held in registers per pass, and - for mesh
  * substrates - the number of time steps between spatial re-sorts of the walker
- * slots (0 = automatic: 512..1024 from the subvoxel size and the step length,
- * shortened to 512 / 256 when the shard is so small that a launch is only a
+ * slots (0 = automatic: 512 steps for the cooperative traversal, 256 / 128 when the shard is so small that a launch is only a
  * few rounds of the GPU's wavefront slots; negative = never), and where the kernels read the
  * gradient samples from (1 = LDS tiles, 2 = scalar loads), how the mesh index is
  * traversed (1 = per lane, 2 = wavefront-cooperative, using the clearance map -

@@ -51,3 +51,15 @@ def test_no_kernel_of_the_library_spills(kernels):
            for n, k in kernels.items()
            if k.get("sgpr_spill_count", 0) > 16 or k.get("vgpr_spill_count", 0) > 0 or k.get("private_segment_fixed_size", 0) > 0}
     assert not bad, bad
+
+
+def test_no_vector_write_right_before_a_dpp_read():
+    """row_bcast / row_fmac issue `v_mov_b64_dpp` / `v_fmac_f64_dpp row_newbcast` through inline assembly,
+    which the compiler's hazard recogniser does not see; the two wait states the hardware needs between a VALU write of
+    the broadcast register and its DPP read hold only while no copy of that register is scheduled between dpp_fence
+    (s_nop 1) and the instruction.  Checked on the shipped code object: every *_dpp instruction of the library."""
+    if not os.path.exists(codeobj_meta.DEFAULT_LIB):
+        pytest.skip("libdsim_hip.so not built")
+    dis = codeobj_meta.disassembly()
+    assert dis.count("_dpp") > 100  # the phase kernels' row broadcasts and the prefix sums are there
+    assert codeobj_meta.dpp_hazards() == []

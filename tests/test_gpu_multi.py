@@ -168,3 +168,23 @@ def test_every_visible_gpu_is_used_by_default(mods):
     sig, pos = simulations.simulation(n, D, gradient, dt, substrates.sphere(5e-6), seed=5, quiet=True, final_pos=True)
     (sig1, pos1), _ = _run(simulations, "0", n, gradient, dt, substrates.sphere(5e-6), {}, final_pos=True)
     assert pos.tobytes() == pos1.tobytes() and sig.tobytes() == sig1.tobytes()
+
+
+def test_two_devices_behind_one_handle_return_the_one_device_bytes(mods, tmp_path):
+    """the in-process twin of test_two_rccl_ranks_on_two_gpus: DSIM_DEVICES=0,1 against 0 - a mesh with the walkers placed
+    by the fill that the two devices share, cut by space, every output of simulation() (needs two GPUs: skipped, never
+    silently green, on the driver's one-GPU box)"""
+    _lib, gradients, simulations, substrates = mods
+    if _lib.device_count() < 2:
+        pytest.skip("one visible GPU")
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 80, np.array([1e9, 4e8]), np.array([[1.0, 0, 0], [0, 0, 1.0]]))
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="intra", n_sv=np.array([6, 6, 6]), quiet=True)
+    n = 150_001
+    out = []
+    for devices in ("0", "0,1"):
+        path = str(tmp_path / ("traj_2gpu_%d.txt" % len(out)))
+        (sig, pos), w = _run(simulations, devices, n, gradient, dt, sub, {}, final_pos=True, all_signals=True)
+        (tot, _), _ = _run(simulations, devices, 2003, gradient, dt, sub, {}, final_pos=True, traj=path)
+        out.append((sig.tobytes(), pos.tobytes(), tot.tobytes(), open(path, "rb").read(), w))
+    assert out[0] == out[1]

@@ -406,7 +406,8 @@ _FULL_SIZE_POSITIONS = {}
 @pytest.mark.parametrize("workload,n,n_meas,t_mid,t_end", [
     ("c5b", 10_000_000, 1, 130, 300), ("c5b", 10_000_000, 4, 130, 300), ("c5b", 10_000_000, 8, 130, 300),
     ("c4", 10_000_000, 1, 130, 300), ("c3", 1_000_000, 1, 130, 300), ("c2", 1_000_000, 32, 400, 1000),
-    ("c5b", 10_000_000, 1, 6000, 10000)])  # the headline run itself: every one of its 10 000 steps
+    ("c5b", 10_000_000, 1, 6000, 10000),  # the headline run itself: every one of its 10 000 steps
+    ("c4", 10_000_000, 1, 6000, 10000), ("c3", 1_000_000, 1, 6000, 10000)])  # [r5] and the other mesh / analytic configs over their full length
 def test_full_size_sample_equals_the_oracle_and_the_partition_does_not_matter(lib, oracle_exact, workload, n, n_meas, t_mid, t_end):
     """BASELINE sizes (configs C5b, C4, C3, C2): all the walkers of the bench workload for the first steps of its
     waveform (C2, and the last C5b case - the run bench.py times: ALL of it, ~11 launches per walker group with their

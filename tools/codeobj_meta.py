@@ -51,6 +51,66 @@ def kernels(lib=DEFAULT_LIB):
     return [k for k in out if "name" in k and "vgpr_count" in k]
 
 
+def disassembly(lib=DEFAULT_LIB):
+    """llvm-objdump -d of the gfx950 code object inside the library (text)"""
+    tmp = tempfile.mkdtemp(prefix="codeobj_")
+    try:
+        work = os.path.join(tmp, os.path.basename(lib))
+        shutil.copy(lib, work)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", work], check=True, capture_output=True)
+        objs = [os.path.join(tmp, f) for f in os.listdir(tmp) if "gfx950" in f]
+        if not objs:
+            raise RuntimeError("no gfx950 code object in %s" % lib)
+        return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", objs[0]], check=True, capture_output=True,
+                              text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _regs(operand):
+    """VGPR numbers an operand names: v5 -> {5}, v[4:5] -> {4, 5}"""
+    m = re.match(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", operand)
+    return {int(m.group(1))} if m else set()
+
+
+def dpp_hazards(lib=DEFAULT_LIB):
+    """DPP instructions whose DPP source (src0) is written by a vector instruction fewer than two wait states earlier
+    (the hardware needs 2 between a VALU write of a VGPR and its read through DPP; hand-written `*_dpp` in inline
+    assembly is invisible to the compiler's hazard recogniser - csrc/dsim_kernels.h row_bcast / row_fmac).  Returns a
+    list of (function, instruction, offending earlier instruction)."""
+    bad, window, func = [], [], "?"
+    for line in disassembly(lib).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line.strip())
+        if m:
+            func, window = m.group(1), []
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins or ins.endswith(":"):
+            window = [] if ins.endswith(":") else window  # a label: control may arrive from elsewhere - start afresh
+            continue
+        parts = ins.replace(",", " ").split()
+        op = parts[0]
+        if "_dpp" in op and len(parts) >= 3:
+            src = _regs(parts[2])
+            states = 0
+            for prev in reversed(window):
+                if states >= 2:
+                    break
+                pp = prev.replace(",", " ").split()
+                if pp[0] == "s_nop":
+                    states += int(pp[1], 0) + 1
+                    continue
+                if pp[0].startswith("v_") and len(pp) > 1 and not pp[0].startswith("v_cmp") and (_regs(pp[1]) & src):
+                    bad.append((func, ins, prev))
+                    break
+                states += 1
+        window = (window + [ins])[-4:]
+    return bad
+
+
 def demangle(names):
     r = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt")] if os.path.exists(os.path.join(LLVM, "llvm-cxxfilt")) else ["c++filt"],
                        input="\n".join(names), capture_output=True, text=True)
