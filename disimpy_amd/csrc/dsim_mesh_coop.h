@@ -350,8 +350,16 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   if (valid) tri = W->surv_tri[idx], tag = W->surv_tag[idx];
   /* the triangle first: its address only needs the survivor, so the nine loads are in flight while the owner's ray
    * comes through the shuffles (a lane without a survivor reads triangle 0) */
-  const double *rec = ms.tri + (int64_t)(int)tri * DS_TRI_STRIDE;
-  const V3 tA = load_v3(rec), tE1 = load_v3(rec + 3), tE2 = load_v3(rec + 6);
+  /* buffer loads: the triangle by its 32-bit byte offset (96 bytes each: 2^25 triangles at most, DevMesh::coop_ok) */
+  const __amdgpu_buffer_rsrc_t tri_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.tri, 0, -1, 0x00020000);
+  const int toff = (int)tri * (DS_TRI_STRIDE * 8);
+  typedef double ds_double2 __attribute__((ext_vector_type(2)));
+  const ds_uint4 t0 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff, 0, 0), t1 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff + 16, 0, 0);
+  const ds_uint4 t2 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff + 32, 0, 0), t3 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff + 48, 0, 0);
+  const uint2 t4 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(tri_rsrc, toff + 64, 0, 0));
+  const ds_double2 d0 = __builtin_bit_cast(ds_double2, t0), d1 = __builtin_bit_cast(ds_double2, t1), d2 = __builtin_bit_cast(ds_double2, t2),
+                   d3 = __builtin_bit_cast(ds_double2, t3);
+  const V3 tA = {d0.x, d0.y, d1.x}, tE1 = {d1.y, d2.x, d2.y}, tE2 = {d3.x, d3.y, __builtin_bit_cast(double, t4)};
   const int owner = (int)(tag & 63u);
   V3 tr0 = {shfl_f64(r0.x, owner), shfl_f64(r0.y, owner), shfl_f64(r0.z, owner)};
   const V3 st = {shfl_f64(step.x, owner), shfl_f64(step.y, owner), shfl_f64(step.z, owner)};
@@ -503,6 +511,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const int lcs = 3 * lk + 2;                 /* log2 of the cell slots per subvoxel, lk > 0 */
     const unsigned cmask = (1u << lcs) - 1u;
     const uint32_t *const dense = lk > 0 ? ms.cell_dense : nullptr;
+    const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.mrec, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dense_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.cell_dense, 0, -1, 0x00020000);
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     /* two cursors: over the 64 first-run slots and over the named extra runs behind them.  A trip of stage 1c gives
      * every lane one of each - the extras are few (a box that straddles a subvoxel face: one walker in ten), so a trip
@@ -519,8 +529,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       if (e.x != 0xffffffffu) {
         STAT_LANE(5);
         STAT_WAVE(5);
-        if (dense != nullptr) { /* one level: the run's slots in the table that has a block for every subvoxel (wave-uniform branch) */
-          const unsigned r0i = dense[e.y], r1i = dense[e.y + ((e.x >> 24) & 15u) + 1u];
+        if (dense != nullptr) { /* one level: the run's slots in the table that has a block for every subvoxel (wave-uniform branch);
+                                 * buffer loads by 32-bit byte offset - the table has fewer than 2^30 slots (upload_mesh_host) */
+          const unsigned r0i = __builtin_amdgcn_raw_buffer_load_b32(dense_rsrc, (int)(e.y << 2), 0, 0);
+          const unsigned r1i = __builtin_amdgcn_raw_buffer_load_b32(dense_rsrc, (int)((e.y + ((e.x >> 24) & 15u) + 1u) << 2), 0, 0);
           first = (int)r0i;
           cnt = (int)(r1i - r0i);
         } else {
@@ -620,12 +632,15 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         /* the records first: their addresses only need the item, so the 8 loads are in flight while the owner's
          * segment comes through the shuffles (a lane without an item reads record 0) */
         const int first_rec = valid ? (int)(it.x & COOP_ITEM_FIRST_MASK) : 0, cnt = valid ? (int)(it.x >> 29) + 1 : 1;
+        /* buffer loads: the index as a scalar resource, a record named by its 32-bit byte offset (one shift per record
+         * instead of a 64-bit address in two VGPRs; 29 bits of record number x 32 bytes wrap at 2^32 bytes, hence the 2^27
+         * records upload_mesh admits) */
         ds_uint4 q0[COOP_ITEM_RECS], q1[COOP_ITEM_RECS];
 #pragma unroll
         for (int u = 0; u < COOP_ITEM_RECS; u++) {
           const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads the first records of the index */
-          q0[u] = ms.mrec[2 * j];
-          q1[u] = ms.mrec[2 * j + 1];
+          q0[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, j << 5, 0, 0);
+          q1[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (j << 5) + 16, 0, 0);
         }
         const int owner = (int)(it.y & 63u);
         /* the owner's segment (plane test: midpoint and half vector as the pairs {m, h} per axis) and its box in the

@@ -656,7 +656,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       mrec.insert(mrec.end(), bu.recs.begin(), bu.recs.end());
     }
-    if (mrec.size() >= 0x20000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* an item of the cooperative traversal names a record in 29 bits */
+    if (mrec.size() >= 0x08000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* the cooperative traversal names a record by a 32-bit byte offset (32 bytes each) */
     cell_start.push_back((uint32_t)mrec.size()); /* end of the last cell */
     if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)mrec.size();
   }
@@ -738,7 +738,7 @@ static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm)
     const uint64_t n_slots = (uint64_t)hm.n_sub << lcs;
     double cap_mb = 4096;
     if (const char *e = getenv("DSIM_DENSE_CELLS_MB")) cap_mb = atof(e);
-    if ((double)(n_slots + 1) * 4.0 <= cap_mb * 1048576.0) {
+    if ((double)(n_slots + 1) * 4.0 <= cap_mb * 1048576.0 && n_slots + 1 < (1ull << 30)) { /* (slots are named by 32-bit byte offsets) */
       uint32_t *before_d = nullptr;
       HIP_TRY(hipMalloc(&dm.cell_dense, (size_t)(n_slots + 1) * sizeof(uint32_t)));
       HIP_TRY(hipMalloc(&before_d, hm.recs_before.size() * sizeof(uint32_t)));
@@ -763,7 +763,7 @@ static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm)
   dm.nz = hm.n[2];
   for (int k = 0; k < 3; k++) dm.inv_h[k] = hm.inv_h[k], dm.inv_l[k] = hm.inv_l[k], dm.lo[k] = hm.lo[k], dm.hi[k] = hm.hi[k];
   dm.set = true;
-  dm.coop_ok = hm.coop_ok;
+  dm.coop_ok = hm.coop_ok && hm.rec.size() / DS_TRI_STRIDE < (1u << 25); /* the cooperative traversal names a triangle by a 32-bit byte offset */
   return DSIM_OK;
 }
 
