@@ -13,6 +13,12 @@ run_one() {
     tests) timeout -k 10 1800 python -m pytest tests -m gpu -q -x "$@" 2>&1 | grep -v "$FILTER" | tail -25 | tee gpurun_out/r05/pytest_last.txt ;;
     ab) bash tools/gpu_ab.sh "$@" | tee -a gpurun_out/r05/ab_log.txt ;;
     sh) "$@" ;;
+    # kernel-trace timeline of the last pass: timeline <tag> <walkers> [bench args]
+    timeline)
+      tag=$1; n=$2; shift; shift
+      O=/tmp/trace_$tag; rm -rf $O
+      timeout -k 5 500 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $PWD/bench.py --workload c5b --walkers $n --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check --no-end-to-end "$@" > gpurun_out/r05/trace_$tag.json 2> gpurun_out/r05/trace_$tag.err
+      python tools/timeline.py $O > gpurun_out/r05/timeline_$tag.txt 2>&1; head -12 gpurun_out/r05/timeline_$tag.txt; tail -12 gpurun_out/r05/timeline_$tag.txt ;;
     # bench lines of the three multi-device paths on the one GPU: default, in-process handle over 0,0, two gloo ranks
     benches)
       O=gpurun_out/r05; tag=${1:-x}

@@ -24,14 +24,18 @@ def main():
     walks = [r for r in rows if r[0].startswith("void walk_kernel") or r[0].startswith("walk_kernel")]
     if not walks:
         raise SystemExit("no walk kernel in the trace")
-    # passes are separated by the longest gaps; take the launches after the last gap > 3x the median duration
-    durs = sorted(w[2] - w[1] for w in walks)
-    med = durs[len(durs) // 2]
-    start_idx = 0
-    for i in range(1, len(walks)):
-        if walks[i][1] - max(w[2] for w in walks[:i]) > 3 * med:
-            start_idx = i
-    last = walks[start_idx:]
+    # a pass over the waveform ends with the signal reduction (one signal_final_kernel per pass): the LAST pass is what lies
+    # between the last two of them (round 4 cut passes at gaps longer than three launches - with launches of 9 ms and 3 ms
+    # between passes that merged two passes into one)
+    finals = [r[1] for r in rows if "signal_final_kernel" in r[0]]
+    if len(finals) >= 2:
+        last = [w for w in walks if finals[-2] < w[1] < finals[-1]]
+    elif finals:
+        last = [w for w in walks if w[1] < finals[-1]]
+    else:
+        last = walks
+    if not last:
+        last = walks
     t0 = last[0][1]
     t1 = max(w[2] for w in last)
     print("# last pass: %d launches of the walk kernel, %.2f ms from the first start to the last end" % (len(last), (t1 - t0) / 1e6))
