@@ -13,6 +13,35 @@ run_one() {
     tests) timeout -k 10 1800 python -m pytest tests -m gpu -q -x "$@" 2>&1 | grep -v "$FILTER" | tail -25 | tee gpurun_out/r05/pytest_last.txt ;;
     ab) bash tools/gpu_ab.sh "$@" | tee -a gpurun_out/r05/ab_log.txt ;;
     sh) "$@" ;;
+    # final evidence of the round, part 1: correctness + the headline lines + kernel trace (-> gpurun_out/r05/final)
+    final1)
+      O=gpurun_out/r05/final; mkdir -p $O
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
+      timeout -k 10 1800 python -m pytest tests -m gpu -q 2>&1 | grep -v "$FILTER" | tail -15 > $O/pytest_gpu.txt
+      timeout -k 10 900 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check --no-end-to-end > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+      find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/c5b_bench_kernel_stats.csv \;
+      rm -rf $O/stats
+      timeout -k 10 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command_line.json 2> $O/bench_driver_command.err
+      timeout -k 10 600 python bench.py --gpus 2 --backend gloo --walkers 2000000 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_gloo_2ranks_1gpu_line.json 2> $O/bench_gloo_2ranks.err
+      DSIM_DEVICES=0,0 timeout -k 10 600 python bench.py --gpus 2 --mode inprocess --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_inprocess_2shards_1gpu_line.json 2> $O/bench_inprocess.err
+      tail -3 $O/pytest_gpu.txt; tail -2 $O/smoke.txt ;;
+    # part 2: counters (separate --pmc passes, --kernel-trace only), stage timers, traversal statistics, rates by size and M
+    final2)
+      O=gpurun_out/r05/final; mkdir -p $O
+      timeout -k 10 1500 python3 tools/pmc_profile.py c5b --walkers 10000000 --tag r05 --passes sq,mem,lds,mix,mix2,fetch,write > $O/pmc_c5b.txt 2>&1
+      for wl in c2 c3 c4; do timeout -k 10 500 python3 tools/pmc_profile.py $wl --walkers 1000000 --tag r05 --passes sq,mem > $O/pmc_$wl.txt 2>&1; done
+      cp profiles/kernel_counters.json profiles/r05_*_pmc.json $O/ 2>/dev/null
+      DSIM_LIB=$PWD/disimpy_amd/csrc/libdsim_hip_timers.so timeout -k 5 300 python tools/mesh_timers.py c5b 1000000 > $O/c5b_phase_timers.txt 2>&1
+      DSIM_LIB=$PWD/disimpy_amd/csrc/libdsim_hip_stats.so timeout -k 5 300 python tools/mesh_stats.py c5b > $O/c5b_traversal_stats.txt 2>&1
+      timeout -k 5 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace1250k -- python3 bench.py --workload c5b --walkers 1250000 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check --no-end-to-end > $O/trace1250k.json 2> $O/trace1250k.err
+      python tools/timeline.py /tmp/trace1250k > $O/two_stream_timeline_1250k.txt 2>&1
+      bash tools/dev/rates.sh "10000000 4" "10000000 8" "10000000 32" "5000000 1" "2500000 1" "1250000 1" "1250000 32" > $O/rates_by_size_and_measurements.txt 2>&1
+      timeout -k 5 900 python tools/dev/parts_rate.py 8 c5b 2>&1 | grep "^part" > $O/spatial_parts_of_8.txt
+      # the two headline lines once more, now that profiles/kernel_counters.json belongs to this build
+      timeout -k 10 900 python bench.py > $O/bench_line_with_counters.json 2> $O/bench_line_with_counters.err
+      python tools/codeobj_meta.py > $O/codeobj_meta.txt 2>&1
+      cat $O/rates_by_size_and_measurements.txt $O/spatial_parts_of_8.txt; tail -30 $O/pmc_c5b.txt ;;
     # kernel-trace timeline of the last pass: timeline <tag> <walkers> [bench args]
     timeline)
       tag=$1; n=$2; shift; shift
