@@ -550,12 +550,12 @@ extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
 
 /* Estimated relative cost of a walker-step at the walker's position in a mesh: 1 + c x (records of the fine cell the
  * position lies in, at most 40).  The records are what a pass of the traversal has to test; a walker in an empty
- * cell - the inside of a soma - finishes its steps in one cheap pass.  c = 0.07 from the measured rates of the eight
+ * cell - the inside of a soma - finishes its steps in one cheap pass.  c = 0.065 from the measured rates of the eight
  * equal-count parts of the refined neuron (1.43e10 in the dendrites, 2.05e10 in the soma) and of the parts cut with
  * c = 0.06 (profiles/history/r05_spatial_parts.txt); DSIM_COST_PER_RECORD overrides it in tuning runs.  Only the CUT depends on
  * it, never a result. */
 static void mesh_walker_cost(const HostMesh &hm, const double *pos, int64_t n, double *w) {
-  double c = 0.07;
+  double c = 0.065;
   if (const char *e = getenv("DSIM_COST_PER_RECORD")) c = atof(e);
   const int lk = hm.lk, k = 1 << lk, ku = lk > 0 ? 2 * k : 1;
   const int per[3] = {ku, ku, k};
