@@ -499,16 +499,20 @@ def secondary_rates(args, device):
             rows.append({"part": k, "walkers": n_here, "value": n_here * T * n_timed / el, "seconds_per_pass": el / n_timed,
                          "walk_kernel_spin_steps_per_s": walk_rate})
         slow = max(rows, key=lambda r: r["seconds_per_pass"])
-        out[key] = {"workload": w["label"], "walkers": slow["walkers"],
-                    "cut": ("the slowest of the %d parts of the spatial cut by estimated cost" % parts if name == "c5b" else
-                            "spatial part 1 of %d" % parts) if parts > 1 else "all",
-                    "value": slow["value"], "unit": "spin-steps/s", "walk_kernel_spin_steps_per_s": slow["walk_kernel_spin_steps_per_s"],
-                    "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=slow["walk_kernel_spin_steps_per_s"])}
         if name == "c5b":
-            out[key]["parts"] = rows
-            # every GPU runs its part at the same time: the job takes as long as its slowest part (+ one all-reduce of 5 int64)
-            out[key]["projected_8_gpu_spin_steps_per_s"] = n * T / slow["seconds_per_pass"]
-            out[key]["note"] = "projection from the parts run one after the other on ONE GPU, not a measurement on 8"
+            # every GPU runs its part at the same time: the job takes as long as its slowest part (+ one all-reduce of 5 int64);
+            # `value` = what ONE GPU of that job delivers: the job's spin-steps / the longest part / the number of GPUs
+            proj = n * T / slow["seconds_per_pass"]
+            out[key] = {"workload": w["label"], "cut": "the %d parts of the spatial cut by estimated cost, run one after the other on this GPU" % parts,
+                        "value": proj / parts, "unit": "spin-steps/s per GPU of the %d-GPU job" % parts,
+                        "projected_8_gpu_spin_steps_per_s": proj, "slowest_part": slow, "parts": rows,
+                        "walk_kernel_spin_steps_per_s": slow["walk_kernel_spin_steps_per_s"],
+                        "note": "projection from the parts run one after the other on ONE GPU, not a measurement on 8",
+                        "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=slow["walk_kernel_spin_steps_per_s"])}
+        else:
+            out[key] = {"workload": w["label"], "walkers": slow["walkers"], "cut": "spatial part 1 of %d" % parts if parts > 1 else "all",
+                        "value": slow["value"], "unit": "spin-steps/s", "walk_kernel_spin_steps_per_s": slow["walk_kernel_spin_steps_per_s"],
+                        "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=slow["walk_kernel_spin_steps_per_s"])}
     return out
 
 

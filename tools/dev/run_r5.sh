@@ -42,6 +42,18 @@ run_one() {
       timeout -k 10 900 python bench.py > $O/bench_line_with_counters.json 2> $O/bench_line_with_counters.err
       python tools/codeobj_meta.py > $O/codeobj_meta.txt 2>&1
       cat $O/rates_by_size_and_measurements.txt $O/spatial_parts_of_8.txt; tail -30 $O/pmc_c5b.txt ;;
+    # the counter passes alone + the headline lines on the build they belong to
+    final3)
+      O=gpurun_out/r05/final; mkdir -p $O
+      timeout -k 10 1500 python3 tools/pmc_profile.py c5b --walkers 10000000 --tag r05 --passes sq,mem,lds,mix,mix2,fetch,write > $O/pmc_c5b.txt 2>&1
+      for wl in c2 c3 c4; do timeout -k 10 500 python3 tools/pmc_profile.py $wl --walkers 1000000 --tag r05 --passes sq,mem > $O/pmc_$wl.txt 2>&1; done
+      cp profiles/kernel_counters.json profiles/r05_*_pmc.json $O/ 2>/dev/null
+      timeout -k 10 900 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
+      timeout -k 10 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command_line.json 2> $O/bench_driver_command.err
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-signal-check --no-end-to-end > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+      find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/c5b_bench_kernel_stats.csv \;
+      rm -rf $O/stats
+      tail -32 $O/pmc_c5b.txt; tail -12 $O/pmc_c4.txt ;;
     # kernel-trace timeline of the last pass: timeline <tag> <walkers> [bench args]
     timeline)
       tag=$1; n=$2; shift; shift

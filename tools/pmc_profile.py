@@ -79,7 +79,7 @@ def main():
         cmd = (["rocprofv3", "--kernel-include-regex", args.match, "--pmc"] + PASSES[name].split()
                + ["--kernel-trace", "--output-format", "csv", "-d", out, "--", "python3", os.path.join(ROOT, "bench.py"),
                   "--steps", "1", "--warmup", "0", "--workload", args.workload, "--walkers", str(args.walkers),
-                  "--no-cpu-baseline", "--no-secondary", "--no-signal-check"] + args.bench_args.split())
+                  "--no-cpu-baseline", "--no-secondary", "--no-signal-check", "--no-end-to-end"] + args.bench_args.split())
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             print("pass %s failed:\n%s\n%s" % (name, r.stdout[-2000:], r.stderr[-2000:]), file=sys.stderr)
