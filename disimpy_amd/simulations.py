@@ -324,8 +324,10 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
     if devices is not None and len(devices) >= 1:
         device = int(devices[0])
     if walker_ids is not None:
-        frames = _initial_positions(0, substrate, seed, True, device, (0, 0))[1] if substrate.type in ("cylinder", "ellipsoid") else None
-        positions = None if positions_all is None else np.ascontiguousarray(np.asarray(positions_all)[walker_ids], dtype=np.float64)
+        if substrate.type != "mesh" or positions_all is None:
+            raise ValueError("walker_ids: a spatial cut of a mesh substrate (needs positions_all)")
+        frames = None
+        positions = np.ascontiguousarray(np.asarray(positions_all)[walker_ids], dtype=np.float64)
     else:
         positions, frames = _initial_positions(n_walkers, substrate, seed, quiet, device, (a, b), dist=dist, devices=devices)
     with _lib.Sim(b - a, gradient, dt, float(step_l), device=device, first_walker=a, devices=devices) as sim:
