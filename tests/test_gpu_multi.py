@@ -188,3 +188,30 @@ def test_two_devices_behind_one_handle_return_the_one_device_bytes(mods, tmp_pat
         (tot, _), _ = _run(simulations, devices, 2003, gradient, dt, sub, {}, final_pos=True, traj=path)
         out.append((sig.tobytes(), pos.tobytes(), tot.tobytes(), open(path, "rb").read(), w))
     assert out[0] == out[1]
+
+
+def test_partition_moves_rng_states_given_before_it_and_keeps_tuning_and_recording(mods):
+    """dsim_partition_by_position on a mesh re-creates the shards with the sizes of the cost-balanced cut: RNG states that
+    were GIVEN (not seeded) before are moved to the new cut, the tuning and the recording switch set before it survive"""
+    _lib, gradients, simulations, substrates = mods
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 40, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    step_l = float(np.sqrt(6 * D * dt))
+    m = golden("sphere_mesh.npz")
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="intra", n_sv=np.array([6, 6, 6]), quiet=True)
+    n = 5001
+    pos = simulations._fill_mesh(n, sub, True, 5)
+    states = _lib.rng_init(77, 1000, n)[::-1].copy()  # any states, not those of a seed
+    out = []
+    for devices in (None, [0, 0, 0]):
+        with _lib.Sim(n, gradient, dt, step_l, devices=devices) as sim:
+            sim.set_tuning(0, 0, 0, 16, 0, 0)
+            sim.set_recording(True)
+            sim.set_rng_states(states)
+            sim.set_mesh(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices)
+            sim.partition_by_position(pos)
+            np.testing.assert_array_equal(sim.rng_states(), states)
+            np.testing.assert_array_equal(sim.positions(), pos)
+            sim.run_mesh(1000, 1e-13, 0.0, 0, 40)
+            out.append((sim.positions().tobytes(), sim.phases().tobytes(), sim.rng_states().tobytes(), sim.recorded(0, 40).tobytes(),
+                        sim.signal_limbs()[0].tobytes()))
+    assert out[0] == out[1]
