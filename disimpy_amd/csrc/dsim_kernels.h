@@ -405,7 +405,7 @@ DSD void iteration_serial(const MeshDev &ms, const SubvoxelWalk &w, const V3 &r0
   }
 }
 
-/* Candidate scan of a run of cells: 4 records (192 bytes) are requested before the first is
+/* Candidate scan of a run of cells: 4 records (128 bytes) are requested before the first is
  * examined, so that the L2 round trips overlap instead of queueing.  The cells are not visited in
  * the reference's order, so a tie - two DIFFERENT triangles at the same smallest distance, of which
  * the reference keeps the one its loops meet first (strict <, simulations.py:981) - is only

@@ -12,9 +12,10 @@
  *             mesh - the fine cells its segment touches, as RUNS of cells along
  *             z (the records of a run are contiguous).  The first run goes to
  *             the queue slot of the owner's own lane, further runs behind;
- *   stage 1c  any lane per run: sv_base + cell_start look-up, the record range
- *             cut into 4-record items (slots from a wave prefix sum);
- *   stage 2   any lane per item: 4 records tested (float32 AABB + plane)
+ *   stage 1c  any lane per run: the record range from the cell table (one level:
+ *             a slot block for every subvoxel), cut into items of COOP_ITEM_RECS
+ *             records (slots from a wave prefix sum);
+ *   stage 2   any lane per item: its records tested (fixed-point box + float32 plane)
  *             against the OWNER's cull box -> survivor pool, slots from wave
  *             ballots;
  *   stage 3   any lane per survivor: fp64 Moller-Trumbore test with the OWNER's
@@ -501,7 +502,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   }
   T_MARK(W, lane, 12);
   wave_sync();
-  /* ---- stages 1c, 2, 3 in rounds: the runs are cut into 4-record items until the item queue
+  /* ---- stages 1c, 2, 3 in rounds: the runs are cut into items of COOP_ITEM_RECS records until the item queue
    * is nearly full, the items are drained into the survivor pool, the pool is flushed (fp64 tests,
    * per-owner minimum) whenever it holds 64 - so no queue size limits the amount of work per pass */
   {
@@ -552,7 +553,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       }
       return make_int2(first, cnt);
     };
-    /* the records of a run as items of four; the last one holds what is left (its count goes in after the loop: the loop
+    /* the records of a run as items of COOP_ITEM_RECS; the last one holds what is left (its count goes in after the loop: the loop
      * itself is one store and two additions per item - its trip count is the longest run of the 64) */
     auto write_items = [&](uint2 *q, int first, int cnt, int nb, unsigned tag) {
       unsigned x = (unsigned)first | ((unsigned)(COOP_ITEM_RECS - 1) << 29);
@@ -617,7 +618,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         if (n_take < 64) break;
       }
       T_MARK(W, lane, 13);
-      /* -- 2: all lanes drain the item queue: float32 AABB + plane culling against the owner's box.
+      /* -- 2: all lanes drain the item queue: fixed-point box + float32 plane culling against the owner's segment.
        * While more runs are coming only full trips of 64 items are drained (the tail of the queue);
        * the remainder waits at the head for the next round */
       const int start = ((cur_a >= 64 && cur_b >= n_extra) || drain_all) ? 0 : (n_items & 63);
@@ -665,7 +666,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           mh_x.x = cb.mhx.x, mh_y.x = cb.mhy.x, mh_z.x = cb.mhz.x, tau = cb.tau;
           b0 = qb.b0, b1 = qb.b1, b2 = qb.b2;
         }
-        /* the four tests without a branch between or around them (with 64 lanes x 4 records somebody always passes
+        /* the tests without a branch between or around them (with 64 lanes x 5 records somebody always passes
          * the box, so a branch only costs mask juggling); a lane without an item tests record 0 for nothing.  Slots beyond
          * the item's count repeat its last record (loads stay unconditional) and do not count.  The results never become
          * a per-lane word: a comparison IS the wave's ballot of it */

@@ -480,7 +480,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
    * cell around it).  Boxes wider than two units take cells i, i + 2, ...  The price is memory: (2k)^2 k cell slots per
    * non-empty subvoxel (slot 2k - 1 of an axis is never used: shifts instead of multiplications) and about 2.5 times
    * the records.  Along z the cells are disjoint, stored fastest with their records back to back, so a run of cells
-   * along z is ONE contiguous range of records.  48-byte records {AABB of the triangle's part inside the cell,
+   * along z is ONE contiguous range of records.  Records (packed to 32 bytes by pack_records) {AABB of the triangle's part inside the cell,
    * supporting plane in float32, triangle, position in the reference's list}:
    *     sv_base[s]           first cell of subvoxel s in cell_start, -1 for an empty subvoxel
    *                          (lk == 0: not used, cell_start is indexed by s itself, nothing overlaps)
