@@ -42,6 +42,14 @@ run_one() {
       timeout -k 10 900 python bench.py > $O/bench_line_with_counters.json 2> $O/bench_line_with_counters.err
       python tools/codeobj_meta.py > $O/codeobj_meta.txt 2>&1
       cat $O/rates_by_size_and_measurements.txt $O/spatial_parts_of_8.txt; tail -30 $O/pmc_c5b.txt ;;
+    # last call of the round: the suite and the two headline lines on the committed tree
+    final4)
+      O=gpurun_out/r05/final; mkdir -p $O
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
+      timeout -k 10 1800 python -m pytest tests -m gpu -q 2>&1 | grep -v "$FILTER" | tail -15 > $O/pytest_gpu.txt
+      timeout -k 10 900 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
+      timeout -k 10 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command_line.json 2> $O/bench_driver_command.err
+      tail -3 $O/pytest_gpu.txt; tail -2 $O/smoke.txt ;;
     # the counter passes alone + the headline lines on the build they belong to
     final3)
       O=gpurun_out/r05/final; mkdir -p $O
