@@ -492,7 +492,7 @@ def secondary_rates(args, device):
             sim, _, _, ids = setup_sim(args, w, n, 0, n, device, part=(k, parts) if parts > 1 else None)
             n_here = n if ids is None else len(ids)
             run_steps(sim, sub, w["frames"], T, 1, None, device, lambda: None)
-            n_timed = 2 if parts == 1 or name != "c5b" else 1
+            n_timed = 2
             el, walk_ms, _, _, sig = run_steps(sim, sub, w["frames"], T, n_timed, None, device, lambda: None)
             sim.close()
             walk_rate = n_here * T / (float(np.mean([m[1] for m in walk_ms])) * 1e-3)
