@@ -59,7 +59,11 @@ DSD uint64_t rng_next(Rng &r) {
  * exact as well - the same double as the 64-bit shift + u64 -> f64 conversion (two conversions,
  * two ldexp and an add on gfx950) in 2 integer and 4 floating-point operations. */
 DSD double u64_to_unit_f64(uint64_t x) {
-  const uint32_t hi = (uint32_t)(x >> 43), lo = (uint32_t)(x >> 11);
+  /* hi from the upper dword alone, behind a barrier the optimiser cannot see through: as a shift of the 64-bit value it
+   * is converted like a 64-bit integer - ldexp(0, 32) plus an addition of zero per draw */
+  uint32_t xh = (uint32_t)(x >> 32);
+  asm volatile("" : "+v"(xh));
+  const uint32_t hi = xh >> 11, lo = (uint32_t)(x >> 11);
   return __builtin_fma((double)lo, 0x1p-53, (double)hi * 0x1p-21);
 }
 
