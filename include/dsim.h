@@ -22,7 +22,9 @@
  *   - mesh: n_faces, n_refs and prod(n_sv) < 2^31, every n_sv[k] in [1, 4096]; the wavefront-cooperative
  *     traversal (the default, mesh_traversal 2) assumes the reference's own subvoxel grid, xs = linspace(0, L, n + 1)
  *     on every axis (substrates.py:506-508): any other boundaries handed in here are walked by the per-lane
- *     traversal (mesh_traversal 1; same results, checked against the boundary values themselves).  A walker whose
+ *     traversal (mesh_traversal 1; same results, checked against the boundary values themselves), as is a mesh of 2^25
+ *     triangles or more (the cooperative traversal names a triangle by a 32-bit byte offset); the fine grid built on top of
+ *     the subvoxel lists may hold at most 2^27 records (32 bytes each, named by byte offsets: dsim_set_mesh fails beyond).  A walker whose
  *     segment reaches more than 31 periodic images away from the voxel, spans more than 64 runs of fine cells or meets
  *     two different triangles at bit-equal distances is redone by its own lane in the reference's order (same
  *     results); the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
