@@ -294,9 +294,10 @@ DSD QBox quantise_box(const CullBox &c, const MeshDev &ms) {
  * m and the half vector h of the segment the end points evaluate to (n.m - c) -+ n.h, so both are beyond the margin tau on
  * the same side iff |n.m - c| - |n.h| > tau.  mh_x = {m.x, h.x} etc.: the two dot products run as three packed
  * operations.  Every rounding / flush-to-zero / NaN case falls on the "keep" side or concerns a walker whose fp64 test
- * cannot hit anyway (a NaN box quantises to an empty one). */
-DSD bool record_survives(const ds_uint4 &q0, const ds_uint4 &q1, unsigned b0, unsigned b1, unsigned b2, const ds_float2 &mh_x,
-                         const ds_float2 &mh_y, const ds_float2 &mh_z, float tau) {
+ * cannot hit anyway (a NaN box quantises to an empty one).  record_tests hands out the two comparisons separately: the
+ * cooperative traversal takes the wave's mask of each (a comparison IS its mask) and combines them on the scalar unit. */
+DSD void record_tests(const ds_uint4 &q0, const ds_uint4 &q1, unsigned b0, unsigned b1, unsigned b2, const ds_float2 &mh_x,
+                      const ds_float2 &mh_y, const ds_float2 &mh_z, float tau, bool &box_ok, bool &plane_ok) {
   /* (elements copied out first: __builtin_bit_cast applied to a vector ELEMENT, `q0.y`, reads element 0 with this compiler) */
   const unsigned rx = q0.x, ry = q0.y, rz = q0.z;
   const ds_short2 d0 = __builtin_bit_cast(ds_short2, b0) - __builtin_bit_cast(ds_short2, rx);
@@ -308,7 +309,14 @@ DSD bool record_survives(const ds_uint4 &q0, const ds_uint4 &q1, unsigned b0, un
   t = __builtin_elementwise_fma((ds_float2){nx, nx}, mh_x, t);
   t = __builtin_elementwise_fma((ds_float2){nz, nz}, mh_z, t); /* {n.m, n.h} */
   const float side = __builtin_fabsf(t.x - pc) - __builtin_fabsf(t.y);
-  return neg == 0u && side <= tau;
+  box_ok = neg == 0u;
+  plane_ok = side <= tau;
+}
+DSD bool record_survives(const ds_uint4 &q0, const ds_uint4 &q1, unsigned b0, unsigned b1, unsigned b2, const ds_float2 &mh_x,
+                         const ds_float2 &mh_y, const ds_float2 &mh_z, float tau) {
+  bool box_ok, plane_ok;
+  record_tests(q0, q1, b0, b1, b2, mh_x, mh_y, mh_z, tau, box_ok, plane_ok);
+  return box_ok && plane_ok;
 }
 DSD CullBox make_cull_box(const V3 &a, const V3 &step, double step_l) {
   /* float32 arithmetic from the start: start point and direction rounded once (half an ulp each), the midpoint one

@@ -92,7 +92,7 @@ struct CoopWave {
   int2 plan_b[64];                 /*   ... first z unit, columns in y | z units << 8 | n0a << 16 | n0b << 24      1.5 KB */
   uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 29, owner | shifts << 6} (1c -> 2)  2.5 KB */
   unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
-  unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6                                                   1.0 KB */
+  unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6 (directly behind surv_tri: stage 2 writes both through one pointer) 1.0 KB */
   unsigned char overflow[64];      /* some work of this owner did not fit a queue: redo serially                     */
   unsigned char tie[64];           /* two different triangles share this owner's smallest d: the reference's order decides */
   int pad[4];
@@ -113,6 +113,10 @@ DSD int wave_inclusive_sum(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
   return v;
 }
+
+/* the wave's mask of a condition.  HIP's __ballot takes an int: the condition is first turned into a 0 / 1 per lane and
+ * compared with 0 again (two vector instructions); the builtin takes the condition as it is - one s_and with exec */
+DSD unsigned long long wave_ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
 DSD double shfl_f64(double v, int src) {
   const long long b = __double_as_longlong(v);
@@ -257,18 +261,21 @@ DSD int plan_columns(int u0, int u1, int lu, int &n_first) {
 }
 
 /* number of runs of the pass (0: the reference's range is empty, nothing is visited), or -1 when the walker cannot be
- * queued: image shifts must fit 6 bits each, a run holds at most 16 cells, and no more than COOP_MAX_RUNS runs */
+ * queued: image shifts must fit 6 bits each, a run holds at most 16 cells, and no more than COOP_MAX_RUNS runs.
+ * Written without early returns: every field of the plan is computed whatever the outcome (integer arithmetic that is safe
+ * on any input), and the outcome is a chain of selects - a return in the middle makes the compiler materialise a default
+ * for every field on every path (some forty v_mov per pass, [r5]) */
 DSD int plan_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, RunPlan &rp) {
-  if (w.ulx <= w.llx || w.uly <= w.lly || w.ulz <= w.llz) return 0;
+  const bool empty = (w.ulx <= w.llx) | (w.uly <= w.lly) | (w.ulz <= w.llz);
   const int nx = ms.nx, ny = ms.ny, nz = ms.nz;
-  if (w.llx < -32 * nx || w.ulx > 32 * nx || w.lly < -32 * ny || w.uly > 32 * ny || w.llz < -32 * nz || w.ulz > 32 * nz) return -1;
+  bool bad = (w.llx < -32 * nx) | (w.ulx > 32 * nx) | (w.lly < -32 * ny) | (w.uly > 32 * ny) | (w.llz < -32 * nz) | (w.ulz > 32 * nz);
   int zu1, na;
-  if (ms.lk > 0) {
+  if (ms.lk > 0) { /* wave-uniform */
     rp.zu0 = w.llz, zu1 = w.ulz - 1;
     na = plan_columns(f.a0, f.a1, ms.lk + 1, rp.n0a);
     rp.nb = plan_columns(f.b0, f.b1, ms.lk + 1, rp.n0b);
   } else {
-    if (w.ulz - w.llz > 16) return -1;
+    bad |= w.ulz - w.llz > 16;
     int z;
     wrap_subvoxel(w.llz, nz, z, rp.zu0);
     wrap_subvoxel(w.ulz - 1, nz, z, zu1);
@@ -278,9 +285,11 @@ DSD int plan_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, 
   }
   rp.a0 = f.a0, rp.b0 = f.b0, rp.c0 = f.c0, rp.c1 = f.c1;
   rp.nc = zu1 - rp.zu0 + 1;
-  if (na > COOP_MAX_RUNS || rp.nb > COOP_MAX_RUNS || rp.nc > COOP_MAX_RUNS) return -1;
-  const int n = na * rp.nb * rp.nc;
-  return n > COOP_MAX_RUNS ? -1 : n;
+  /* each factor is checked on its own, so the product of three accepted factors cannot overflow */
+  const unsigned n = (unsigned)na * (unsigned)rp.nb * (unsigned)rp.nc;
+  bad |= ((unsigned)na > (unsigned)COOP_MAX_RUNS) | ((unsigned)rp.nb > (unsigned)COOP_MAX_RUNS) | ((unsigned)rp.nc > (unsigned)COOP_MAX_RUNS) |
+         (n > (unsigned)COOP_MAX_RUNS);
+  return empty ? 0 : (bad ? -1 : (int)n);
 }
 
 /* column i of an axis (plan_columns): the subvoxel (absolute, any image) and the cell inside it */
@@ -436,7 +445,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     finished = true;
     act = false;
   }
-  if (__ballot(act) == 0ULL) return finished;
+  if (wave_ballot(act) == 0ULL) return finished;
   COOP_PRIO_LOOKUPS();
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
   W->best_tri[lane] = 0xffffffffu;
@@ -450,10 +459,16 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   /* ---- stage 1: owners work out their cull box and list the runs of fine cells their segment touches.  Box and
    * ray stay in the owner's registers (cb0, r0, step: unchanged until stage 4); the other lanes read
    * them with __shfl, so every lane has to be active wherever a shuffle is executed. */
-  CullBox cb0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, 0.0f};
-  QBox qb0 = {0u, 0u, 0u};
+  /* segment, box and plan of a lane that is NOT in the pass are never used (no run, no item, no survivor names it as the
+   * owner; a lane without an item reads lane 0's and throws the result away): their registers are left as they are
+   * ("set", for the compiler, by an asm that emits nothing; zeroing them was 19 v_mov per pass) */
+  CullBox cb0;
+  QBox qb0;
+  RunPlan rp;
+  asm volatile("" : "=v"(cb0.lox), "=v"(cb0.loy), "=v"(cb0.loz), "=v"(cb0.hix), "=v"(cb0.hiy), "=v"(cb0.hiz), "=v"(cb0.mhx), "=v"(cb0.mhy),
+               "=v"(cb0.mhz), "=v"(cb0.tau), "=v"(qb0.b0), "=v"(qb0.b1), "=v"(qb0.b2));
+  asm volatile("" : "=v"(rp.a0), "=v"(rp.b0), "=v"(rp.c0), "=v"(rp.c1), "=v"(rp.zu0), "=v"(rp.nb), "=v"(rp.nc), "=v"(rp.n0a), "=v"(rp.n0b));
   int n_runs = 0;
-  RunPlan rp = {0, 0, 0, 0, 0, 1, 1, 0, 0};
   const MeshDev &ms = p.mesh;
   if (act) {
     iter_idx++;
@@ -591,7 +606,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           STAT_WAVE(3);
         }
         const int incl = wave_inclusive_sum(nb);
-        const unsigned long long fits = __ballot(n_items + incl <= COOP_ITEM_CAP);
+        const unsigned long long fits = wave_ballot(n_items + incl <= COOP_ITEM_CAP);
         const int n_take = fits == ~0ULL ? 64 : (int)__ffsll((long long)~fits) - 1; /* the lanes that fit form a prefix */
         if (n_take == 0) {
           if (n_items > 0) { /* drain first, then retry with an empty queue */
@@ -637,11 +652,11 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
          * instead of a 64-bit address in two VGPRs; 29 bits of record number x 32 bytes wrap at 2^32 bytes, hence the 2^27
          * records upload_mesh admits) */
         ds_uint4 q0[COOP_ITEM_RECS], q1[COOP_ITEM_RECS];
+        const int rec_off = (ABLATE(4) ? 0 : first_rec) << 5; /* 4: every lane reads the first records of the index */
 #pragma unroll
-        for (int u = 0; u < COOP_ITEM_RECS; u++) {
-          const int j = ABLATE(4) ? u : first_rec + min(u, cnt - 1); /* 4: every lane reads the first records of the index */
-          q0[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, j << 5, 0, 0);
-          q1[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (j << 5) + 16, 0, 0);
+        for (int u = 0; u < COOP_ITEM_RECS; u++) { /* one address, ten immediate offsets */
+          q0[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_off + u * 32, 0, 0);
+          q1[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_off + u * 32 + 16, 0, 0);
         }
         const int owner = (int)(it.y & 63u);
         /* the owner's segment (plane test: midpoint and half vector as the pairs {m, h} per axis) and its box in the
@@ -668,15 +683,21 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         }
         /* the tests without a branch between or around them (with 64 lanes x 5 records somebody always passes
          * the box, so a branch only costs mask juggling); a lane without an item tests record 0 for nothing.  Slots beyond
-         * the item's count repeat its last record (loads stay unconditional) and do not count.  The results never become
+         * the item's count hold the records that follow in the index (the loads stay unconditional and share one address
+         * register; the index ends with COOP_ITEM_RECS - 1 records of padding, upload_mesh_host) and do not count.  The results never become
          * a per-lane word: a comparison IS the wave's ballot of it */
         const bool on = valid && !ABLATE(3) && !ABLATE(4);
+        const unsigned long long on_mask = (ABLATE(3) || ABLATE(4)) ? 0ULL : wave_ballot(valid);
         bool alive[COOP_ITEM_RECS];
         unsigned long long mask[COOP_ITEM_RECS], any = 0ULL;
 #pragma unroll
         for (int u = 0; u < COOP_ITEM_RECS; u++) {
-          alive[u] = on & (cnt > u) & record_survives(q0[u], q1[u], b0, b1, b2, mh_x, mh_y, mh_z, tau); /* & not &&: no branches */
-          mask[u] = __ballot(alive[u]);
+          bool box_ok, plane_ok;
+          record_tests(q0[u], q1[u], b0, b1, b2, mh_x, mh_y, mh_z, tau, box_ok, plane_ok);
+          /* the mask of every comparison on its own, combined on the scalar unit (the mask of a combined condition would
+           * first be turned into a 0 / 1 per lane and compared again: two vector instructions per record) */
+          mask[u] = on_mask & wave_ballot(cnt > u) & wave_ballot(box_ok) & wave_ballot(plane_ok);
+          alive[u] = on & (cnt > u) & box_ok & plane_ok; /* & not &&: no branches */
           any |= mask[u];
         }
         /* the survivors' slots from the ballots (survivors in lower lanes first): the pool's fill level stays in a
@@ -691,15 +712,26 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             total += (int)__popcll(mask[u]);
           }
           int slot = n_surv + (int)below;
+          if (n_surv + total <= COOP_SURV_CAP) { /* wave-uniform, and all but always: nobody has to look at its slot */
+            unsigned *st = &W->surv_tri[slot];
 #pragma unroll
-          for (int u = 0; u < COOP_ITEM_RECS; u++) {
-            if (!alive[u]) continue;
-            if (slot < COOP_SURV_CAP) {
-              W->surv_tri[slot] = q0[u].w;
-              W->surv_tag[slot] = it.y;
-            } else
-              W->overflow[owner] = 1;
-            slot++;
+            for (int u = 0; u < COOP_ITEM_RECS; u++) {
+              if (!alive[u]) continue;
+              st[0] = q0[u].w;
+              st[COOP_SURV_CAP] = it.y; /* surv_tag follows surv_tri */
+              st++;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < COOP_ITEM_RECS; u++) {
+              if (!alive[u]) continue;
+              if (slot < COOP_SURV_CAP) {
+                W->surv_tri[slot] = q0[u].w;
+                W->surv_tag[slot] = it.y;
+              } else
+                W->overflow[owner] = 1;
+              slot++;
+            }
           }
           n_surv = min(n_surv + total, COOP_SURV_CAP);
         }

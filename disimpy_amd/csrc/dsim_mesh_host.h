@@ -355,7 +355,8 @@ static float record_quantum(const double *const b3[3], const int64_t n_sv[3]) {
 /* 32-byte device records from the float32 ones: lo rounded down, hi rounded up in the EXACT value of x * qs (double
  * arithmetic on the float32 constant; 1e-6 quanta of slack for its own rounding), clamped into [0, 32767] */
 static void pack_records(const std::vector<HostRecord> &recs, float qs, std::vector<uint4> &out) {
-  out.resize(std::max<size_t>(recs.size(), 1) * 2, make_uint4(0u, 0u, 0u, 0u));
+  /* + 8 records of padding: the cooperative traversal loads an item's full width whatever its count (dsim_mesh_coop.h, stage 2) */
+  out.resize((recs.size() + 8) * 2, make_uint4(0u, 0u, 0u, 0u));
   auto q = [&](float x, bool up) -> uint32_t {
     const double v = (double)x * (double)qs;
     double r = up ? std::ceil(v + 1e-6) : std::floor(v - 1e-6);
@@ -656,7 +657,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       mrec.insert(mrec.end(), bu.recs.begin(), bu.recs.end());
     }
-    if (mrec.size() >= 0x08000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* the cooperative traversal names a record by a 32-bit byte offset (32 bytes each) */
+    if (mrec.size() + 8 >= 0x08000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* the cooperative traversal names a record by a 32-bit byte offset (32 bytes each) */
     cell_start.push_back((uint32_t)mrec.size()); /* end of the last cell */
     if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)mrec.size();
   }
