@@ -435,16 +435,14 @@ template <int KA>
 DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, bool clear, const WalkParams &p_arg,
                         const double *xs, const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
   const WalkParams &p = fresh_params<KA>(p_arg);
-  bool finished = false;
-  bool act = in_step && step_l > 0 && iter_idx < p.max_iter;
-  if (in_step && !act) finished = true; /* while-condition false on entry */
-  if (act && clear) {
-    /* no triangle within the step length (clearance map): this pass of the loop finds min_d > step_l
-     * whatever the direction (simulations.py:986-987) - counted, but not traversed */
-    iter_idx++;
-    finished = true;
-    act = false;
-  }
+  /* (plain boolean algebra, no branches: the conditions stay lane masks on the scalar unit)
+   * looping: the while-condition holds on entry.  skip: no triangle within the step length (clearance map) - this pass of the
+   * loop finds min_d > step_l whatever the direction (simulations.py:986-987): counted, but not traversed */
+  const bool looping = in_step & (step_l > 0) & (iter_idx < p.max_iter);
+  const bool skip = looping & clear;
+  const bool act = looping & !clear;
+  bool finished = in_step & !act; /* while-condition false on entry, or skipped */
+  iter_idx += skip ? 1 : 0;
   if (wave_ballot(act) == 0ULL) return finished;
   COOP_PRIO_LOOKUPS();
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
@@ -647,7 +645,10 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         if (valid) it = W->items[idx];
         /* the records first: their addresses only need the item, so the 8 loads are in flight while the owner's
          * segment comes through the shuffles (a lane without an item reads record 0) */
-        const int first_rec = valid ? (int)(it.x & COOP_ITEM_FIRST_MASK) : 0, cnt = valid ? (int)(it.x >> 29) + 1 : 1;
+        /* a lane without an item: count 0, no record of it counts */
+        const int first_rec = valid ? (int)(it.x & COOP_ITEM_FIRST_MASK) : 0;
+        int cnt = (valid && !ABLATE(3) && !ABLATE(4)) ? (int)(it.x >> 29) + 1 : 0;
+        asm volatile("" : "+v"(cnt)); /* (opaque: `cnt > u` below stays ONE comparison instead of valid & (count > u)) */
         /* buffer loads: the index as a scalar resource, a record named by its 32-bit byte offset (one shift per record
          * instead of a 64-bit address in two VGPRs; 29 bits of record number x 32 bytes wrap at 2^32 bytes, hence the 2^27
          * records upload_mesh admits) */
@@ -686,8 +687,6 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
          * the item's count hold the records that follow in the index (the loads stay unconditional and share one address
          * register; the index ends with COOP_ITEM_RECS - 1 records of padding, upload_mesh_host) and do not count.  The results never become
          * a per-lane word: a comparison IS the wave's ballot of it */
-        const bool on = valid && !ABLATE(3) && !ABLATE(4);
-        const unsigned long long on_mask = (ABLATE(3) || ABLATE(4)) ? 0ULL : wave_ballot(valid);
         bool alive[COOP_ITEM_RECS];
         unsigned long long mask[COOP_ITEM_RECS], any = 0ULL;
 #pragma unroll
@@ -696,8 +695,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           record_tests(q0[u], q1[u], b0, b1, b2, mh_x, mh_y, mh_z, tau, box_ok, plane_ok);
           /* the mask of every comparison on its own, combined on the scalar unit (the mask of a combined condition would
            * first be turned into a 0 / 1 per lane and compared again: two vector instructions per record) */
-          mask[u] = on_mask & wave_ballot(cnt > u) & wave_ballot(box_ok) & wave_ballot(plane_ok);
-          alive[u] = on & (cnt > u) & box_ok & plane_ok; /* & not &&: no branches */
+          mask[u] = wave_ballot(cnt > u) & wave_ballot(box_ok) & wave_ballot(plane_ok);
+          alive[u] = __builtin_amdgcn_inverse_ballot_w64(mask[u]); /* the mask itself selects the lanes that write */
           any |= mask[u];
         }
         /* the survivors' slots from the ballots (survivors in lower lanes first): the pool's fill level stays in a
@@ -748,17 +747,12 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   if (act) {
     const WalkParams &p = fresh_params<KA>(p_arg);
     const MeshDev &ms = p.mesh;
-    double d = DS_INF;
-    int tri = 0;
-    bool redo = serial || W->overflow[lane];
-    if (!redo) {
-      const unsigned long long bd = W->best_d[lane];
-      if (bd != 0x7ff0000000000000ULL) {
-        d = __longlong_as_double((long long)bd);
-        tri = (int)W->best_tri[lane];
-        redo = d <= step_l && W->tie[lane]; /* the reference's visiting order decides between equal distances */
-      }
-    }
+    /* straight-line: the minimum as it stands (its initial pattern IS +inf: nothing hit), the triangle that goes with it, and
+     * whether the walker has to go through the pass on its own - queues overflowed, or two triangles at the same distance
+     * within the step (the reference's visiting order decides between them) */
+    double d = __longlong_as_double((long long)W->best_d[lane]);
+    int tri = (int)W->best_tri[lane];
+    const bool redo = serial | (W->overflow[lane] != 0) | ((d <= step_l) & (W->tie[lane] != 0));
     if (redo) {
       /* this walker's whole iteration again, by its own lane, exactly as the reference does it */
       STAT_LANE(9);
