@@ -102,6 +102,9 @@ struct CoopWave {
 #endif
 };
 
+static_assert(offsetof(CoopWave, surv_tag) == offsetof(CoopWave, surv_tri) + COOP_SURV_CAP * sizeof(unsigned),
+              "stage 2 writes a survivor's triangle and tag through one pointer");
+
 /* inclusive prefix sum over the 64 lanes with DPP moves (VALU only, no LDS crossbar): Kogge-Stone
  * inside every row of 16 lanes, then the row totals are carried into the following rows */
 DSD int wave_inclusive_sum(int v) {
