@@ -206,29 +206,26 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
         ids_all = _lib.partition_walkers(positions_all, world, cost)  # parts of equal estimated cost
         kw = {"walker_ids": ids_all[rank], "positions_all": positions_all}
         a, b = 0, len(ids_all[rank])
-    lines = {"first": True}
-
     def traj_sink(t0, t1, rows):
-        """this rank's (steps, n_local, 3) -> whole lines on rank 0"""
-        if t0 == 0 and lines["first"]:
-            lines["first"] = False
-            start = kw["positions_all"] if ids_all is not None else None
-            if start is None:  # the ranks' initial rows in walker order
-                mine = simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, shard_range(n_walkers, rank, world))[0]
-                mine = np.zeros((b - a, 3)) if mine is None else np.asarray(mine, dtype=np.float64)
-                start = _gather_rows(mine, dist, device) if world > 1 else mine
-            if rank == 0:
-                _lib.write_traj_line(traj, np.ascontiguousarray(start, dtype=np.float64), append=False)
-        cols = np.ascontiguousarray(rows.transpose(1, 0, 2))  # (n_local, steps, 3): the gather runs over walkers
-        whole = _gather_rows(cols, dist, device) if world > 1 else cols
+        """this rank's part of the trajectories file -> whole lines on rank 0.  ``t0 == -1``: the start line, ``rows`` =
+        the (n_local, 3) initial positions ``_simulate`` hands to the device (NOT computed a second time here: a mesh
+        with ``init_pos="uniform"`` draws them from the global NumPy stream, which a second call would find advanced);
+        otherwise (steps, n_local, 3), the positions after the steps [t0, t1)."""
+        if t0 < 0:
+            cols = np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, 1, 3))
+        else:
+            cols = np.ascontiguousarray(rows.transpose(1, 0, 2))  # (n_local, steps, 3): the gather runs over walkers
+        whole = _gather_rows(cols, dist, device)
         if rank == 0:
             if ids_all is not None:
                 out = np.empty_like(whole)
                 out[np.concatenate(ids_all)] = whole
                 whole = out
-            for k in range(t1 - t0):
-                _lib.write_traj_line(traj, np.ascontiguousarray(whole[:, k, :]), append=True)
+            for k in range(whole.shape[1]):
+                _lib.write_traj_line(traj, np.ascontiguousarray(whole[:, k, :]), append=t0 >= 0)
 
+    # one process: the library's own writer (dsim_write_traj) - the sink is for gathering the ranks' columns
+    sink = traj_sink if traj and world > 1 else None
     if b == a:  # more ranks than walkers: nothing to simulate here, but the collectives still need this rank
         if world > 1 and ids_all is None and substrate.type == "mesh" and isinstance(substrate.init_pos, str) and substrate.init_pos in ("intra", "extra"):
             simulations._initial_positions(n_walkers, substrate, seed, True, device or 0, (a, b), dist=dist)  # the shared fill
@@ -237,6 +234,7 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
         if traj:  # take part in the gathers of every range of steps
             n_t = gradient.shape[1]
             chunk = max(1, min(n_t, (1 << 30) // (24 * max(1, n_walkers))))
+            traj_sink(-1, 0, np.zeros((0, 3)))
             for t0 in range(0, n_t, chunk):
                 traj_sink(t0, min(n_t, t0 + chunk), np.zeros((min(n_t, t0 + chunk) - t0, 0, 3)))
     else:
@@ -244,7 +242,7 @@ def simulation_sharded(n_walkers, diffusivity, gradient, dt, substrate, seed=123
                                     device=device or 0, walker_range=None if ids_all is not None else (a, b),
                                     dist=dist if world > 1 and ids_all is None else None,
                                     need_phases=bool(all_signals), need_positions=bool(final_pos),
-                                    traj_sink=traj_sink if traj else None, **kw)
+                                    traj_sink=sink, **kw)
     if "limbs" in res:  # the exact integer sums of the device reduction: the total does not depend on the split
         c, s, nexc = reduce_signal_exact(res["limbs"], res["n_exceeded"], dist, device)
     else:

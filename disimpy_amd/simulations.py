@@ -300,8 +300,9 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
     dsim_create_multi: the shards run concurrently, per-walker outputs come back in order; a mesh run cuts them by
     space).  ``walker_ids`` (ascending) instead of a range: this process's part of a spatial cut of ALL walkers
     (sharding.simulation_sharded), ``positions_all`` then holds the initial positions of all of them.
-    ``traj_sink(t0, t1, rows)``: called per range of recorded steps with this shard's positions (t1 - t0, 3, n_local)
-    instead of writing the trajectories file here (the ranks of a sharded job gather their columns).
+    ``traj_sink(t0, t1, rows)``: called once with ``t0 = -1`` and this shard's (n_local, 3) initial positions, then per
+    range of recorded steps with its positions (t1 - t0, n_local, 3), instead of writing the trajectories file here (the
+    ranks of a sharded job gather their columns).
 
     Returns a dict with the device-reduced signal sums and, on request,
     per-walker outputs of this range.  Walker i always gets RNG state i and
@@ -345,8 +346,12 @@ def _simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj, quiet
                 sim.partition_by_position(pos)
             else:
                 sim.set_positions(pos)
-        if traj and traj_sink is None:
-            _write_traj(traj, "w", np.zeros((b - a, 3)) if positions is None else np.asarray(positions))
+        if traj:  # the start line: the positions the device got (never computed a second time)
+            start = np.zeros((b - a, 3)) if positions is None else np.asarray(positions, dtype=np.float64)
+            if traj_sink is None:
+                _write_traj(traj, "w", start)
+            else:
+                traj_sink(-1, 0, start)
         if traj:
             # the trajectories file needs the positions after every step: the device records them
             # and hands them over once per range of steps (<= 64 MB) instead of once per step

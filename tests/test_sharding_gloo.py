@@ -281,11 +281,16 @@ def _oracle_simulate(n_walkers, diffusivity, gradient, dt, substrate, seed, traj
         ma = dict(vertices=substrate.vertices, faces=substrate.faces, xs=substrate.xs, ys=substrate.ys, zs=substrate.zs, n_sv=substrate.n_sv,
                   subvoxel_indices=substrate.subvoxel_indices, triangle_indices=substrate.triangle_indices)
         g = o.geom(MESH, mesh=ma, max_iter=max_iter, epsilon=epsilon)
-        pos = np.ascontiguousarray(np.asarray(substrate.init_pos if positions_all is None else positions_all)[ids], dtype=np.float64)
+        start = positions_all
+        if start is None:  # like the real _simulate: given rows, or (init_pos="uniform") draws of the global NumPy stream
+            start = substrate.init_pos if isinstance(substrate.init_pos, np.ndarray) else \
+                simulations._initial_positions(n_walkers, substrate, seed, True, 0, (0, n_walkers))[0]
+        pos = np.ascontiguousarray(np.asarray(start)[ids], dtype=np.float64)
     st = o.rng_states(n_walkers, seed)[ids].copy()
     pos0 = pos.copy()
     ph, exc, tr = o.run(g, gradient, dt, step_l, pos, st, want_traj=bool(traj))
     if traj and traj_sink is not None:
+        traj_sink(-1, 0, pos0)  # the start line: the positions this run began with
         traj_sink(0, gradient.shape[1], tr)
     elif traj:
         simulations._write_traj_python(traj, "w", pos0)
@@ -415,3 +420,33 @@ def test_sharded_simulation_writes_the_trajectories_file_and_cuts_a_mesh_by_spac
         np.testing.assert_array_equal(pos, one["positions"])
     assert open(path, "rb").read() == open(want_path, "rb").read()
     assert len(open(path).read().splitlines()) == 26
+
+
+def test_one_process_writes_the_positions_the_walkers_started_from(tmp_path, monkeypatch):
+    """without a process group (world = 1) simulation_sharded(traj=...) takes the single-process writer,
+    and the start line holds the positions the walkers were given - on a mesh with init_pos="uniform" those are draws of
+    the global NumPy stream (disimpy/simulations.py:1347), which a second look would find advanced"""
+    from disimpy_amd import gradients, sharding, simulations, substrates
+
+    calls = []
+    real = simulations._initial_positions
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    monkeypatch.setattr(simulations, "_simulate", _oracle_simulate)
+    monkeypatch.setattr(simulations, "_initial_positions", counted)
+    m = np.load(os.path.join(ROOT, "tests", "golden", "sphere_mesh.npz"))
+    sub = substrates.mesh(m["vertices"], m["faces"], True, padding=np.zeros(3) + 1e-6, init_pos="uniform", n_sv=np.array([4, 4, 4]), quiet=True)
+    gradient, dt = gradients.pgse(10e-3, 40e-3, 25, np.array([1e9]), np.array([[1.0, 0, 0]]))
+    n, seed = 6, 7
+    path = str(tmp_path / "traj.txt")
+    _, pos = sharding.simulation_sharded(n, 2e-9, gradient, dt, sub, seed=seed, dist=None, final_pos=True, traj=path)
+    assert len(calls) == 1  # the initial positions are worked out once
+    lines = [np.array(l.split(), dtype=np.float64).reshape(n, 3) for l in open(path).read().splitlines()]
+    assert len(lines) == 26
+    np.random.seed(seed)
+    np.testing.assert_array_equal(lines[0], np.random.random((n, 3)) * sub.voxel_size)
+    assert not np.array_equal(lines[1], lines[0])
+    np.testing.assert_array_equal(lines[-1], pos)
