@@ -512,9 +512,12 @@ def secondary_rates(args, device):
             out[key] = {"workload": w["label"], "cut": "the %d parts of the spatial cut by estimated cost, run one after the other on this GPU" % parts,
                         "value": proj / parts, "unit": "spin-steps/s per GPU of the %d-GPU job" % parts,
                         "projected_%d_gpu_spin_steps_per_s" % parts: proj, "slowest_part": slow, "parts": rows,
-                        "walk_kernel_spin_steps_per_s": slow["walk_kernel_spin_steps_per_s"],
-                        "note": "projection from the parts run one after the other on ONE GPU, not a measurement on %d" % parts,
-                        "roofline": valu_roofline(name, M=w["gradient"].shape[0], walk_rate=slow["walk_kernel_spin_steps_per_s"])}
+                        # the walk kernels of ALL parts: sum of their spin-steps / sum of their kernel times.  (No VALU roofline
+                        # here: the counters in profiles/ are those of the whole substrate, and a part - the soma's walkers,
+                        # say - spends a different number of instructions per step)
+                        "walk_kernel_spin_steps_per_s": sum(r["walkers"] for r in rows) * T
+                        / sum(r["walkers"] * T / r["walk_kernel_spin_steps_per_s"] for r in rows),
+                        "note": "projection from the parts run one after the other on ONE GPU, not a measurement on %d" % parts}
         else:
             out[key] = {"workload": w["label"], "walkers": slow["walkers"], "cut": "spatial part 1 of %d" % parts if parts > 1 else "all",
                         "value": slow["value"], "unit": "spin-steps/s", "walk_kernel_spin_steps_per_s": slow["walk_kernel_spin_steps_per_s"],
@@ -535,6 +538,9 @@ def valu_roofline(workload, M, walk_rate):
     use = prof if ok else {}
     valu_ws = use.get("valu_per_wave_step")
     rate = valu_ws * walk_rate / 64.0 if valu_ws else None
+    if rate is not None and rate > VALU_PEAK:  # counters that do not belong to what ran here: say nothing rather than > 1
+        valu_ws, rate, ok = None, None, False
+        use = {}
     return {"bound": "valu", "kernel": use.get("kernel"), "valu_per_wave_step": valu_ws, "valu_busy_measured": use.get("valu_busy"),
             "salu_per_wave_step": use.get("salu_per_wave_step"), "lds_per_wave_step": use.get("lds_per_wave_step"),
             "achieved": rate, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": (rate / VALU_PEAK) if rate else None,

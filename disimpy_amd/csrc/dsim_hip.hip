@@ -610,8 +610,9 @@ extern "C" int dsim_mesh_walker_cost(const double *vertices, int64_t n_vertices,
   if (!pos || !out_cost || n < 0) return fail(DSIM_ERR_INVALID, "dsim_mesh_walker_cost: bad argument");
   HostMesh hm;
   DevMesh none;
+  /* the fine grid only (its k follows from step_l): the cost model never looks at the clearance map */
   int rc = upload_mesh(none, nullptr, vertices, n_vertices, faces, n_faces, xs, ys, zs, n_sv, subvoxel_indices, triangle_indices, n_refs, step_l,
-                       nullptr, &hm);
+                       nullptr, &hm, false);
   if (rc) return rc;
   mesh_walker_cost(hm, pos, n, out_cost);
   return DSIM_OK;
@@ -777,29 +778,60 @@ extern "C" int dsim_partition_by_position(dsim_handle h, const double *pos) {
   if (rc) return rc;
   bool resize = false;
   for (size_t k = 0; k < G; k++) resize = resize || start[k + 1] - start[k] != h->shards[k]->n;
-  h->shard_ids.assign(G, std::vector<int64_t>());
+  /* Prepared aside, committed at the end: the new shards - or, with unchanged sizes, the new device copies of
+   * the index lists - are made first, and the handle (shards, shard_ids, shard_off) changes only when EVERY shard has succeeded.
+   * A failure on one device (an allocation, say) frees what was prepared and leaves the handle as it was. */
+  std::vector<std::vector<int64_t>> new_ids(G);
+  std::vector<dsim_sim *> fresh(G, nullptr); /* resize: the shards with their new numbers of walkers (no mesh yet) */
+  std::vector<int64_t *> fresh_ids(G, nullptr); /* else: the device arrays the old shards will take */
   rc = multi_each(h, [&](int k, dsim_sim *old, int64_t) -> int {
-    h->shard_ids[(size_t)k].assign(ids.begin() + start[(size_t)k], ids.begin() + start[(size_t)k + 1]);
-    dsim_sim *sh = old;
-    if (resize) { /* the shard again, with its new number of walkers; the device copy of the index moves over */
-      sh = nullptr;
-      int rc1 = dsim_create(&sh, old->device, start[(size_t)k + 1] - start[(size_t)k], h->first, h->M, h->T, h->keep_g[0].data(), h->keep_g[1].data(),
+    std::vector<int64_t> &mine = new_ids[(size_t)k];
+    mine.assign(ids.begin() + start[(size_t)k], ids.begin() + start[(size_t)k + 1]);
+    if (resize) {
+      dsim_sim *sh = nullptr;
+      int rc1 = dsim_create(&sh, old->device, (int64_t)mine.size(), h->first, h->M, h->T, h->keep_g[0].data(), h->keep_g[1].data(),
                             h->keep_g[2].data(), h->dt, h->step_l);
       if (rc1) return rc1;
-      sh->mesh = old->mesh;
-      old->mesh = DevMesh();
+      fresh[(size_t)k] = sh;
       const int *t = h->keep_tune;
       rc1 = dsim_set_tuning(sh, t[0], t[1], t[2], t[3], t[4], t[5]);
       if (rc1 == DSIM_OK && h->keep_recording) rc1 = dsim_set_recording(sh, 1);
-      (void)dsim_destroy(old);
-      h->shards[(size_t)k] = sh;
       if (rc1) return rc1;
+      sh->first = h->first; /* slot i holds walker first + ids[i] */
+      return dsim_set_walker_ids(sh, mine.data());
     }
-    sh->first = h->first; /* slot i holds walker first + ids[i] */
-    return dsim_set_walker_ids(sh, h->shard_ids[(size_t)k].data());
+    HIP_TRY(hipSetDevice(old->device));
+    HIP_TRY(hipMalloc(&fresh_ids[(size_t)k], std::max<size_t>(1, mine.size()) * sizeof(int64_t)));
+    HIP_TRY(hipMemcpy(fresh_ids[(size_t)k], mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    return DSIM_OK;
   });
-  for (size_t k = 0; k < G; k++) h->shard_off[k] = start[k];
-  if (rc) return rc;
+  if (rc) { /* nothing of the handle has been touched */
+    const std::string why = g_err;
+    for (size_t k = 0; k < G; k++) {
+      if (fresh[k]) (void)dsim_destroy(fresh[k]);
+      if (fresh_ids[k]) {
+        (void)hipSetDevice(h->shards[k]->device);
+        (void)hipFree(fresh_ids[k]);
+      }
+    }
+    return fail(rc, "%s", why.c_str());
+  }
+  for (size_t k = 0; k < G; k++) { /* commit: cannot fail */
+    dsim_sim *old = h->shards[k];
+    if (resize) {
+      fresh[k]->mesh = old->mesh; /* the device copy of the index moves over */
+      old->mesh = DevMesh();
+      (void)dsim_destroy(old);
+      h->shards[k] = fresh[k];
+    } else {
+      (void)hipSetDevice(old->device);
+      if (old->walker_ids) (void)hipFree(old->walker_ids);
+      old->walker_ids = fresh_ids[k];
+      old->first = h->first;
+    }
+    h->shard_off[k] = start[k];
+  }
+  h->shard_ids = std::move(new_ids);
   rc = dsim_set_positions(h, pos);
   if (rc) return rc;
   if (h->seeded) return dsim_rng_init_device(h, h->seed_value);

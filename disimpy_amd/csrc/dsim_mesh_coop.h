@@ -365,7 +365,8 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
    * comes through the shuffles (a lane without a survivor reads triangle 0) */
   /* buffer loads: the triangle by its 32-bit byte offset (96 bytes each: 2^25 triangles at most, DevMesh::coop_ok) */
   const __amdgpu_buffer_rsrc_t tri_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.tri, 0, -1, 0x00020000);
-  const int toff = (int)tri * (DS_TRI_STRIDE * 8);
+  /* an UNSIGNED 32-bit byte offset: 2^25 triangles x 96 bytes pass 2^31 (a signed product would overflow from 22 369 622 triangles on) */
+  const int toff = (int)(tri * (unsigned)(DS_TRI_STRIDE * 8));
   typedef double ds_double2 __attribute__((ext_vector_type(2)));
   const ds_uint4 t0 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff, 0, 0), t1 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff + 16, 0, 0);
   const ds_uint4 t2 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff + 32, 0, 0), t3 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, toff + 48, 0, 0);

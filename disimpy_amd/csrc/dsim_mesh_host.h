@@ -409,7 +409,7 @@ static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm)
 static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, int64_t n_vertices, const int64_t *faces,
                        int64_t n_faces, const double *xs, const double *ys, const double *zs, const int64_t n_sv[3],
                        const int64_t *subvoxel_indices, const int64_t *triangle_indices, int64_t n_refs, double step_l,
-                       HostFineGrid *host_only = nullptr, HostMesh *build_only = nullptr) {
+                       HostFineGrid *host_only = nullptr, HostMesh *build_only = nullptr, bool want_clearance = true) {
   if (!vertices || !faces || !xs || !ys || !zs || !n_sv || !subvoxel_indices || (!triangle_indices && n_refs))
     return fail(DSIM_ERR_INVALID, "mesh: null argument");
   if (n_faces <= 0 || n_vertices <= 0 || n_faces > INT32_MAX || n_refs > INT32_MAX || n_refs < 0)
@@ -685,7 +685,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
   hm.lk = lk;
   hm.qs = qs;
   hm.n_sub = n_sub;
-  if (step_l > 0) { /* the walk's clearance map (not used by the fill kernel, which passes step_l = 0) */
+  if (step_l > 0 && want_clearance) { /* the walk's clearance map (not used by the fill kernel, which passes step_l = 0, nor by the cost model) */
     const double *bb[3] = {xs, ys, zs};
     build_clearance_map(vertices, faces, n_faces, bb, n_sv, step_l, hm.cidx, hm.cbits, hm.clear_lf, hm.clear_frac);
   }
@@ -740,17 +740,26 @@ static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm)
     double cap_mb = 4096;
     if (const char *e = getenv("DSIM_DENSE_CELLS_MB")) cap_mb = atof(e);
     if ((double)(n_slots + 1) * 4.0 <= cap_mb * 1048576.0 && n_slots + 1 < (1ull << 30)) { /* (slots are named by 32-bit byte offsets) */
+      /* The table is an optimisation: the two-level look-up (cell_dense == nullptr) is complete without it.  When its memory
+       * is not to be had - several shards or ranks on one device multiply it - the error is cleared and the shard goes on
+       * with the compact arrays; before_d is freed on every path. */
       uint32_t *before_d = nullptr;
-      HIP_TRY(hipMalloc(&dm.cell_dense, (size_t)(n_slots + 1) * sizeof(uint32_t)));
-      HIP_TRY(hipMalloc(&before_d, hm.recs_before.size() * sizeof(uint32_t)));
-      hipError_t e = hipMemcpyAsync(before_d, hm.recs_before.data(), hm.recs_before.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+      hipError_t e = hipMalloc(&dm.cell_dense, (size_t)(n_slots + 1) * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMalloc(&before_d, hm.recs_before.size() * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMemcpyAsync(before_d, hm.recs_before.data(), hm.recs_before.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
       if (e == hipSuccess) {
         expand_cells_kernel<<<(unsigned)((n_slots + 256) / 256), 256, 0, stream>>>(dm.sv_base, dm.cell_start, before_d, lcs, n_slots, dm.cell_dense);
         e = hipGetLastError();
       }
       if (e == hipSuccess) e = hipStreamSynchronize(stream);
-      (void)hipFree(before_d);
-      if (e != hipSuccess) return fail(DSIM_ERR_HIP, "dense cell table: %s", hipGetErrorString(e));
+      if (before_d) (void)hipFree(before_d);
+      if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError(); /* clear the sticky error: the run continues on the two-level path */
+        if (dm.cell_dense) (void)hipFree(dm.cell_dense);
+        dm.cell_dense = nullptr;
+      } else if (e != hipSuccess) {
+        return fail(DSIM_ERR_HIP, "dense cell table: %s", hipGetErrorString(e));
+      }
     }
   }
   HIP_TRY(hipMalloc(&dm.bounds, hm.bounds.size() * sizeof(double)));
