@@ -115,12 +115,19 @@ DSD void normalize3(V3 &v) {
   ds_div3(&v.x, &v.y, &v.z, length);
 }
 
-/* simulations.py:121-138 */
-DSD V3 random_step(Rng &r, const double *log_tab, const double *cos_tab) {
+/* simulations.py:121-138 without the final normalisation (the caller's: the cooperative mesh kernel normalises the new
+ * directions of the walkers that start a step and of those that were reflected in the previous pass in ONE place) */
+DSD V3 random_step_raw(Rng &r, const double *log_tab, const double *cos_tab) {
   V3 s;
   s.x = rng_normal_f64(r, log_tab, cos_tab);
   s.y = rng_normal_f64(r, log_tab, cos_tab);
   s.z = rng_normal_f64(r, log_tab, cos_tab);
+  return s;
+}
+
+/* simulations.py:121-138 */
+DSD V3 random_step(Rng &r, const double *log_tab, const double *cos_tab) {
+  V3 s = random_step_raw(r, log_tab, cos_tab);
   normalize3(s);
   return s;
 }
@@ -178,7 +185,9 @@ DSD double ray_triangle_intersection_check(const V3 &A, const V3 &E1, const V3 &
   return DS_NAN;
 }
 
-/* simulations.py:278-311; updates r0, step and the (possibly flipped) normal */
+/* simulations.py:278-311; updates r0, step and the (possibly flipped) normal.  NORM = false: the reflected direction is
+ * left as computed, the caller normalises it (normalize3) before anything reads it */
+template <bool NORM = true>
 DSD void reflection(V3 &r0, V3 &step, double d, V3 &n, double epsilon) {
   V3 is = {__builtin_fma(d, step.x, r0.x), __builtin_fma(d, step.y, r0.y), __builtin_fma(d, step.z, r0.z)};
   V3 v = {is.x - r0.x, is.y - r0.y, is.z - r0.z};
@@ -193,7 +202,7 @@ DSD void reflection(V3 &r0, V3 &step, double d, V3 &n, double epsilon) {
   step.x = (__builtin_fma(m2dp, n.x, v.x) + is.x) - is.x;
   step.y = (__builtin_fma(m2dp, n.y, v.y) + is.y) - is.y;
   step.z = (__builtin_fma(m2dp, n.z, v.z) + is.z) - is.z;
-  normalize3(step);
+  if (NORM) normalize3(step);
   r0.x = __builtin_fma(epsilon, n.x, is.x);
   r0.y = __builtin_fma(epsilon, n.y, is.y);
   r0.z = __builtin_fma(epsilon, n.z, is.z);

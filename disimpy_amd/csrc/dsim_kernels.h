@@ -734,6 +734,7 @@ DSD void walk_body(const WalkParams &p_arg) {
       V3 step = {0, 0, 0};
       double sl = 0;
       int64_t iter_idx = 0;
+      bool need_norm = false; /* `step` holds a direction that has not been normalised yet */
       for (int passes = 0;; passes++) {
         const WalkParams &p = fresh_params<KA>(p_arg); /* nothing of the launch parameters stays in SGPRs across passes */
         const bool want = live && k_lane < kt;
@@ -746,13 +747,18 @@ DSD void walk_body(const WalkParams &p_arg) {
             gpre_xy = *reinterpret_cast<const double2 *>(g);
             gpre_z = g[2];
           }
-          step = random_step(rng, log_tab, cos_tab);
+          step = DSIM_DEFER_NORM ? random_step_raw(rng, log_tab, cos_tab) : random_step(rng, log_tab, cos_tab);
+          need_norm = DSIM_DEFER_NORM;
           sl = p.step_l;
           iter_idx = 0;
           in_step = true;
         }
+        if (DSIM_DEFER_NORM && need_norm) { /* the new directions: of a started step, or of the reflection of the previous pass */
+          normalize3(step);
+          need_norm = false;
+        }
         T_MARK(coop, lane, 0);
-        const bool finished = coop_iteration<KA>(r, step, sl, iter_idx, in_step, clear, p, xs, ys, zs, rng, coop, lane);
+        const bool finished = coop_iteration<KA>(r, step, sl, iter_idx, in_step, clear, p, xs, ys, zs, rng, coop, lane, need_norm);
         clear = false; /* only the first pass of a step starts a full step length away from its start */
         if (in_step && finished) {
           if (iter_idx >= p.max_iter) exc = true; /* simulations.py:999-1002 */

@@ -435,9 +435,18 @@ DSD bool walker_is_clear(const MeshDev &ms, const V3 &r) {
  * no longer holds).  The caller lets every lane run through its own time steps at its own pace
  * (a wavefront then needs about mean-iterations-per-step passes per step, not the maximum over
  * its 64 lanes). */
+/* [r6] need_norm (out): this lane's walker was reflected and goes on - its new direction is NOT yet normalised; the caller
+ * does that at the head of the next pass, in the same instructions that normalise the directions of the walkers that start
+ * a step there (the two sets are disjoint: the normalisation ran twice per pass, at 44 and at 15 of 64 lanes, now once). */
+#ifndef DSIM_DEFER_NORM
+#define DSIM_DEFER_NORM 1
+#endif
+#ifndef DSIM_LOOKUPS_TOGETHER
+#define DSIM_LOOKUPS_TOGETHER 1
+#endif
 template <int KA>
 DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, bool in_step, bool clear, const WalkParams &p_arg,
-                        const double *xs, const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane) {
+                        const double *xs, const double *ys, const double *zs, Rng &rng, CoopWave *W, int lane, bool &need_norm) {
   const WalkParams &p = fresh_params<KA>(p_arg);
   /* (plain boolean algebra, no branches: the conditions stay lane masks on the scalar unit)
    * looping: the while-condition holds on entry.  skip: no triangle within the step length (clearance map) - this pass of the
@@ -599,9 +608,31 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
             eb = make_run(ms, o, q, (int)(m >> 6));
           }
         }
-        const int2 ra = look_up(ea);
-        int2 rb = make_int2(0, 0);
-        if (extras) rb = look_up(eb);
+        int2 ra, rb = make_int2(0, 0);
+#if DSIM_LOOKUPS_TOGETHER
+        if (dense != nullptr) { /* (wave-uniform) [r6] the slots of both runs asked for before either answer is waited for, and
+                                 * without a branch per lane: a lane without a run reads slot 0 twice - an empty range */
+          const bool va = ea.x != 0xffffffffu, vb = eb.x != 0xffffffffu;
+          const unsigned a0 = va ? ea.y : 0u, a1 = va ? ea.y + ((ea.x >> 24) & 15u) + 1u : 0u;
+          const unsigned r0a = __builtin_amdgcn_raw_buffer_load_b32(dense_rsrc, (int)(a0 << 2), 0, 0);
+          const unsigned r1a = __builtin_amdgcn_raw_buffer_load_b32(dense_rsrc, (int)(a1 << 2), 0, 0);
+          if (extras) {
+            const unsigned b0 = vb ? eb.y : 0u, b1 = vb ? eb.y + ((eb.x >> 24) & 15u) + 1u : 0u;
+            const unsigned r0b = __builtin_amdgcn_raw_buffer_load_b32(dense_rsrc, (int)(b0 << 2), 0, 0);
+            const unsigned r1b = __builtin_amdgcn_raw_buffer_load_b32(dense_rsrc, (int)(b1 << 2), 0, 0);
+            rb = make_int2((int)r0b, (int)(r1b - r0b));
+          }
+          ra = make_int2((int)r0a, (int)(r1a - r0a));
+#ifdef DSIM_STATS
+          if (va) { STAT_LANE(5); STAT_WAVE(5); }
+          if (extras && vb) { STAT_LANE(5); STAT_WAVE(5); }
+#endif
+        } else
+#endif
+        {
+          ra = look_up(ea);
+          if (extras) rb = look_up(eb);
+        }
         const int nba = n_items_of(min(ra.y, 8192)), nbb = n_items_of(min(rb.y, 8192)), nb = nba + nbb;
         if (nb > 0) {
           STAT_LANE(3);
@@ -776,11 +807,17 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       V3 n = load_v3(ms.tri + (int64_t)tri * DS_TRI_STRIDE + 9);
       const bool reflect = p.perm_prob < rng_uniform_f64(rng);
       if (reflect)
-        reflection(r0, step, d, n, p.eps);
+        reflection<!DSIM_DEFER_NORM>(r0, step, d, n, p.eps);
       else
         crossing(r0, step, d, n, p.eps);
       step_l -= d;
       if (!(step_l > 0 && iter_idx < p.max_iter)) finished = true; /* the while-condition of the next pass */
+      if (DSIM_DEFER_NORM && reflect) {
+        if (finished) /* (rare: the hit used the step up, or max_iter) the caller moves the walker along `step` right away */
+          normalize3(step);
+        else
+          need_norm = true;
+      }
     }
   }
   T_MARK(W, lane, 8);

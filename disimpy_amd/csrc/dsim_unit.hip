@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void mesh_pass_kernel(const WalkParams p, cons
     bool done = false;
     for (int pass = 0; a.n_pass == 0 || pass < a.n_pass; pass++) {
       if (__ballot(live && !done) == 0ULL) break;
-      const bool fin = coop_iteration<0>(r, step, sl, iter_idx, live && !done, false, p, xs, ys, zs, rng, coop, lane);
+      bool need_norm = false; /* the caller's part of the contract: a reflected direction is normalised before anything reads it */
+      const bool fin = coop_iteration<0>(r, step, sl, iter_idx, live && !done, false, p, xs, ys, zs, rng, coop, lane, need_norm);
+      if (need_norm) normalize3(step);
       if (live && !done && fin) done = true;
     }
     flags = done ? 1 : 0;
