@@ -113,6 +113,8 @@ struct MeshDev {
   const uint32_t *clear_bits;
   int clear_lf;
   int nx, ny, nz;
+  float inv_nx, inv_ny, inv_nz;  /* [r6] 1 / n as float32: the periodic image of a subvoxel coordinate by one multiplication (wrap_subvoxel) */
+  float pad_;
   double inv_hx, inv_hy, inv_hz; /* n / voxel_size: first guess only      */
   double inv_lx, inv_ly, inv_lz; /* 1 / voxel_size: first guess only      */
   double x0, y0, z0, x1, y1, z1; /* xs[0], ys[0], zs[0], xs[nx], ys[ny], zs[nz] */

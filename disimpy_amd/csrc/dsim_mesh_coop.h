@@ -229,12 +229,18 @@ DSD void segment_query(const MeshDev &ms, const V3 &r0, const V3 &step, double s
   fine_limits(tn2, tx2, q2, sw.llz, sw.ulz, ms.lk, fr.c0, fr.c1);
 }
 
-/* wrapped subvoxel coordinate and image number of an absolute subvoxel coordinate */
-DSD void wrap_subvoxel(int s, int n, int &x, int &sn) {
+/* wrapped subvoxel coordinate and image number of an absolute subvoxel coordinate: sn = floor(s / n) (Python: math.floor,
+ * simulations.py:661).  [r6] By one float32 multiplication instead of an integer division (~20 instructions, four of them
+ * quarter-rate 32-bit multiplies; three divisions per run on the packed cylinders, whose walkers are nearly all in a
+ * periodic image along z after a few hundred steps - positions are never wrapped, like the reference's): (s + 1/2) / n is
+ * at least 1 / (2 n) >= 1.2e-4 away from every integer (n <= 4096, upload_mesh), |s| <= 33 n wherever the result is used
+ * (plan_runs sends anything beyond +-32 voxels to the serial pass), so s + 1/2 is exact and the product is off by less than
+ * 33 x 2^-22 = 8e-6: the floor is the exact one.  inv_n = 1.0f / n from the host (MeshDev). */
+DSD void wrap_subvoxel(int s, int n, float inv_n, int &x, int &sn) {
   x = s, sn = 0;
   if (s < 0 || s > n - 1) {
-    sn = floor_div(s, n);
-    x = s - sn * n;
+    sn = (int)__builtin_floorf(((float)s + 0.5f) * inv_n);
+    x = s - __mul24(sn, n);
   }
 }
 
@@ -280,8 +286,8 @@ DSD int plan_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, 
   } else {
     bad |= w.ulz - w.llz > 16;
     int z;
-    wrap_subvoxel(w.llz, nz, z, rp.zu0);
-    wrap_subvoxel(w.ulz - 1, nz, z, zu1);
+    wrap_subvoxel(w.llz, nz, ms.inv_nz, z, rp.zu0);
+    wrap_subvoxel(w.ulz - 1, nz, ms.inv_nz, z, zu1);
     na = f.a1 - f.a0 + 1;
     rp.nb = f.b1 - f.b0 + 1;
     rp.n0a = rp.n0b = 0;
@@ -289,7 +295,8 @@ DSD int plan_runs(const MeshDev &ms, const SubvoxelWalk &w, const FineRange &f, 
   rp.a0 = f.a0, rp.b0 = f.b0, rp.c0 = f.c0, rp.c1 = f.c1;
   rp.nc = zu1 - rp.zu0 + 1;
   /* each factor is checked on its own, so the product of three accepted factors cannot overflow */
-  const unsigned n = (unsigned)na * (unsigned)rp.nb * (unsigned)rp.nc;
+  /* (24-bit multiplies - full rate; v_mul_lo_u32 runs at a quarter of it: a factor beyond 2^24 is rejected by its own check) */
+  const unsigned n = __umul24(__umul24((unsigned)na, (unsigned)rp.nb), (unsigned)rp.nc);
   bad |= ((unsigned)na > (unsigned)COOP_MAX_RUNS) | ((unsigned)rp.nb > (unsigned)COOP_MAX_RUNS) | ((unsigned)rp.nc > (unsigned)COOP_MAX_RUNS) |
          (n > (unsigned)COOP_MAX_RUNS);
   return empty ? 0 : (bad ? -1 : (int)n);
@@ -314,11 +321,11 @@ DSD uint2 make_run(const MeshDev &ms, int owner, const RunPlan &rp, int j) {
   const int lk = ms.lk, k = 1 << lk, km = k - 1;
   int ia = 0, ib = 0, iz = j;
   if (j > 0) { /* j < 64: (j + 1/2) / n is at least 1/128 away from every integer, the reciprocal is good to 1e-6 */
-    const int bc = rp.nb * rp.nc;
+    const int bc = __mul24(rp.nb, rp.nc);
     ia = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)bc));
-    const int rem = j - ia * bc;
+    const int rem = j - __mul24(ia, bc);
     ib = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)rp.nc));
-    iz = rem - ib * rp.nc;
+    iz = rem - __mul24(ib, rp.nc);
   }
   const int zu = rp.zu0 + iz;
   int sa, sb, ca = 0, cb = 0;
@@ -329,18 +336,19 @@ DSD uint2 make_run(const MeshDev &ms, int owner, const RunPlan &rp, int j) {
     sa = rp.a0 + ia, sb = rp.b0 + ib;
   }
   int x, snx, y, sny, z, snz, cs, ce;
-  wrap_subvoxel(sa, ms.nx, x, snx);
-  wrap_subvoxel(sb, ms.ny, y, sny);
+  wrap_subvoxel(sa, ms.nx, ms.inv_nx, x, snx);
+  wrap_subvoxel(sb, ms.ny, ms.inv_ny, y, sny);
   if (lk > 0) {
-    wrap_subvoxel(zu, ms.nz, z, snz);
+    wrap_subvoxel(zu, ms.nz, ms.inv_nz, z, snz);
     cs = max(rp.c0, zu * k), ce = min(rp.c1, zu * k + km);
   } else {
     snz = zu;
-    const int lo = zu * ms.nz;
+    const int lo = __mul24(zu, ms.nz);
     cs = max(rp.c0, lo), ce = min(rp.c1, lo + ms.nz - 1);
     z = cs - lo;
   }
-  const unsigned sv = (unsigned)((x * ms.ny + y) * ms.nz + z);
+  /* x < nx, y < ny <= 4096 each and fewer than 2^31 subvoxels in all: 24-bit multiplies (full rate) give the exact index */
+  const unsigned sv = __umul24(__umul24((unsigned)x, (unsigned)ms.ny) + (unsigned)y, (unsigned)ms.nz) + (unsigned)z;
   /* cell slots of a subvoxel: (2k)^2 k, column-major with z fastest (lk == 0: the subvoxel is the cell) */
   const unsigned cell = lk > 0 ? (unsigned)(((((ca << (lk + 1)) | cb) << lk) | (cs & km))) : 0u;
   return make_uint2((unsigned)owner | ((unsigned)(snx + 32) << 6) | ((unsigned)(sny + 32) << 12) | ((unsigned)(snz + 32) << 18) |
@@ -420,11 +428,11 @@ DSD bool walker_is_clear(const MeshDev &ms, const V3 &r) {
   const int ix = clearance_cell(r.x - ms.x0, ms.inv_lx, ms.nx << lf);
   const int iy = clearance_cell(r.y - ms.y0, ms.inv_ly, ms.ny << lf);
   const int iz = clearance_cell(r.z - ms.z0, ms.inv_lz, ms.nz << lf);
-  const int blk = ms.clear_idx[((ix >> lf) * ms.ny + (iy >> lf)) * ms.nz + (iz >> lf)];
+  const int blk = ms.clear_idx[__umul24(__umul24((unsigned)(ix >> lf), (unsigned)ms.ny) + (unsigned)(iy >> lf), (unsigned)ms.nz) + (unsigned)(iz >> lf)];
   if (blk < 0) return true; /* nothing within reach of the whole subvoxel */
   const unsigned bit = (unsigned)(((((ix & m) << lf) | (iy & m)) << lf) | (iz & m));
-  const unsigned words = lf >= 2 ? 1u << (3 * lf - 5) : 1u;
-  const uint32_t w = ms.clear_bits[(size_t)blk * words + (bit >> 5)];
+  const int lw = lf >= 2 ? 3 * lf - 5 : 0; /* log2 of the dwords per block */
+  const uint32_t w = ms.clear_bits[((size_t)blk << lw) + (bit >> 5)];
   return ((w >> (bit & 31u)) & 1u) == 0u;
 }
 
@@ -537,9 +545,12 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const int lk = ms.lk;
     const int lcs = 3 * lk + 2;                 /* log2 of the cell slots per subvoxel, lk > 0 */
     const unsigned cmask = (1u << lcs) - 1u;
-    const uint32_t *const dense = lk > 0 ? ms.cell_dense : nullptr;
+    /* the one-level table of a run's records: lk > 0 the dense cell table (a slot block for every subvoxel), lk == 0 cell_start
+     * itself - indexed by the subvoxel, [r6] read through the same paired buffer loads (entries named by 32-bit byte offsets:
+     * fewer than 2^30 subvoxels) */
+    const uint32_t *const dense = lk > 0 ? ms.cell_dense : ((unsigned)(ms.nx * ms.ny * ms.nz) < (1u << 30) ? ms.cell_start : nullptr);
     const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.mrec, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dense_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.cell_dense, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dense_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dense, 0, -1, 0x00020000);
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     /* two cursors: over the 64 first-run slots and over the named extra runs behind them.  A trip of stage 1c gives
      * every lane one of each - the extras are few (a box that straddles a subvoxel face: one walker in ten), so a trip
@@ -590,7 +601,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     auto n_items_of = [](int n) -> int {
       if (COOP_ITEM_RECS == 4) return (n + 3) >> 2;
       if (COOP_ITEM_RECS == 8) return (n + 7) >> 3;
-      return (int)(((unsigned)(n + COOP_ITEM_RECS - 1) * (unsigned)(65536 / COOP_ITEM_RECS + 1)) >> 16); /* exact below 2^14 */
+      return (int)(__umul24((unsigned)(n + COOP_ITEM_RECS - 1), (unsigned)(65536 / COOP_ITEM_RECS + 1)) >> 16); /* exact below 2^14 */
     };
     while (cur_a < 64 || cur_b < n_extra) {
       /* -- 1c: up to 64 first runs and 64 extra runs per trip, one of each per lane */

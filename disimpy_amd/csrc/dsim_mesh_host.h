@@ -795,6 +795,8 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.nx = dm.nx;
   m.ny = dm.ny;
   m.nz = dm.nz;
+  m.inv_nx = 1.0f / (float)std::max(1, dm.nx), m.inv_ny = 1.0f / (float)std::max(1, dm.ny), m.inv_nz = 1.0f / (float)std::max(1, dm.nz);
+  m.pad_ = 0.f;
   m.inv_hx = dm.inv_h[0];
   m.inv_hy = dm.inv_h[1];
   m.inv_hz = dm.inv_h[2];
