@@ -1386,7 +1386,7 @@ struct WalkGroup {
  * phase workgroup in only where a walk workgroup has retired - one per CU while the walk kernel runs, several once it
  * drains: 1.08e10, and 9.35e9 against 8.83e9 at 1.25e6 walkers (profiles/history/r04_ab_m32_phase_kernel_dpp.txt: 0 / 20 /
  * 28 / 32 / 40 / 48 / 64 KB asked for give 1.025-1.037 / 1.025 / 1.077 / 1.081 / 1.065 / 1.001 / 1.05e10).
- * walk_lds: dynamic LDS of one walk workgroup.  DSIM_PHASE_LDS (bytes) overrides it in tuning runs. */
+ * walk_lds: LDS of one walk workgroup (static + dynamic).  DSIM_PHASE_LDS (bytes) overrides it in tuning runs. */
 static size_t phase_lds_reserve(size_t walk_lds) {
   if (const char *e = getenv("DSIM_PHASE_LDS")) return (size_t)std::min<long>(std::max<long>(atol(e), 0L), 64L * 1024L); /* a launch cannot ask for more */
   const size_t cu = 160 * 1024, granule = 1280;
@@ -1505,7 +1505,7 @@ static int run_own_clock(dsim_sim *h, WalkParams p, const MeshDev &clear_map, bo
       HIP_TRY(hipEventRecord((*g.ev)[*g.ev_used + 1], v->stream));
       *g.ev_used += 2;
       h->last_launches++;
-      const size_t lds_p = std::max<size_t>(4 * PHASE_ROWS_LDS_PER_WAVE, n_groups > 1 ? phase_lds_reserve(lds) : 0); /* 32 KB of staging; see phase_lds_reserve */
+      const size_t lds_p = std::max<size_t>(4 * PHASE_ROWS_LDS_PER_WAVE, n_groups > 1 ? phase_lds_reserve(lds + DS_STATIC_LDS_BYTES) : 0); /* 32 KB of staging; see phase_lds_reserve */
       const int grid_p = grid_for(v->n, 256);
       for (int m0 = 0; m0 < h->M; m0 += mb_phase) {
         const int mc = std::min(mb_phase, h->M - m0);
@@ -1747,7 +1747,8 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   const int coop = geom == GEOM_MESH && h->mesh_traversal != 1 && h->mesh.coop_ok;
   const int block = h->block_size;
   int n_bounds = geom == GEOM_MESH ? h->mesh.nx + h->mesh.ny + h->mesh.nz + 3 : 0;
-  const size_t lds_fixed = (size_t)(DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES + ((n_bounds + 1) & ~1)) * sizeof(double) +
+  /* (the whole LDS of a workgroup: the static tables of the random step + the dynamic part asked for at the launch) */
+  const size_t lds_fixed = DS_STATIC_LDS_BYTES + (size_t)((n_bounds + 1) & ~1) * sizeof(double) +
                            (coop ? (size_t)(block / 64) * sizeof(CoopWave) : 0);
   const bool coop4 = coop && mb <= COOP4_MAX_MB;
   if (coop4) {
@@ -1764,6 +1765,7 @@ static int run_impl(dsim_sim *h, int geom, WalkParams p, int32_t t_begin, int32_
   p.tile_steps = tile;
   size_t lds = lds_fixed + (coop4 ? 0 : (size_t)tile * mb * 4 * sizeof(double));
   if (lds > (coop ? 160u : 64u) * 1024u) return fail(DSIM_ERR_INVALID, "LDS request %zu bytes too large (n_sv too fine?)", lds);
+  lds -= DS_STATIC_LDS_BYTES; /* what the launches ask for: the dynamic part */
   int grid = grid_for(h->n, block);
   /* runs of 8 walker groups (2048 walkers) per XCD: measured on C5b with the counting sort's 64^3 bins, 1.25e6 walkers:
    * runs of 1 / 2 / 4 / 8 / 16 / 32 / 64 / 128 groups give 1.085 / 1.13 / 1.18 / 1.20 / 1.18 / 1.14 / 1.10 / 0.91e10

@@ -70,6 +70,7 @@ typedef short ds_short2 __attribute__((ext_vector_type(2)));
 enum { GEOM_FREE = 0, GEOM_SPHERE = 1, GEOM_CYLINDER = 2, GEOM_ELLIPSOID = 3, GEOM_MESH = 4 };
 
 #define DS_TRI_STRIDE 12 /* doubles per triangle record */
+#define DS_STATIC_LDS_BYTES ((DS_LOG_TABLE_DOUBLES + DS_COS_TABLE_DOUBLES) * 8) /* walk_body's static LDS (the tables of the random step) */
 
 struct MeshDev {
   const double *tri;       /* [n_faces][12] {A, E1 = B - A, E2 = C - A, unit normal}: the normal is
@@ -625,10 +626,26 @@ DSD void dpp_fence(double &a, double &b, double &c) { asm volatile("s_nop 1" : "
 
 /* measurements M0 .. M0 + 15 of one time step: gx, gy, gz hold, in lane j of every row, the gradient sample of
  * measurement M0 + j; the same operations in the same order as the fused kernels (walk_body):
- * inner = fma(gz, z, fma(gx, x, gy * y)), phase = fma(gdt, inner, phase) */
+ * inner = fma(gz, z, fma(gx, x, gy * y)), phase = fma(gdt, inner, phase).
+ * [r6] Four measurements at a time, their chains interleaved: a DPP operation must not read a register a vector instruction
+ * wrote within the last two issue slots, and with ONE chain every second instruction waited for that (three s_nop per
+ * measurement in the shipped code of rounds 4-5); and gy * y as fma(gy, y, +0) on the DPP form itself instead of a
+ * broadcast move followed by a multiplication.  The fma returns the product's own rounding; only an exact zero product
+ * can come out as +0 where the multiplication gives -0, and a zero of either sign leaves the next fma's result - and in
+ * the end the phase, which is never -0 (it starts at +0 and x + (-x) = +0) - bit for bit the same. */
 template <int M0, int J, int MB>
 DSD void phase_step16(double (&ph)[MB], double gx, double gy, double gz, double x, double y, double z, double gdt) {
-  if constexpr (J < 16 && M0 + J < MB) {
+  if constexpr (J < 16 && M0 + J < MB && MB % 4 == 0) {
+    double i0 = 0.0, i1 = 0.0, i2 = 0.0, i3 = 0.0;
+    row_fmac<J>(i0, gy, y), row_fmac<J + 1>(i1, gy, y), row_fmac<J + 2>(i2, gy, y), row_fmac<J + 3>(i3, gy, y);
+    row_fmac<J>(i0, gx, x), row_fmac<J + 1>(i1, gx, x), row_fmac<J + 2>(i2, gx, x), row_fmac<J + 3>(i3, gx, x);
+    row_fmac<J>(i0, gz, z), row_fmac<J + 1>(i1, gz, z), row_fmac<J + 2>(i2, gz, z), row_fmac<J + 3>(i3, gz, z);
+    ph[M0 + J] = __builtin_fma(gdt, i0, ph[M0 + J]);
+    ph[M0 + J + 1] = __builtin_fma(gdt, i1, ph[M0 + J + 1]);
+    ph[M0 + J + 2] = __builtin_fma(gdt, i2, ph[M0 + J + 2]);
+    ph[M0 + J + 3] = __builtin_fma(gdt, i3, ph[M0 + J + 3]);
+    phase_step16<M0, J + 4, MB>(ph, gx, gy, gz, x, y, z, gdt);
+  } else if constexpr (J < 16 && M0 + J < MB) { /* (instantiated, never run: fewer than four accumulators take other paths) */
     double inner = row_bcast<J>(gy) * y;
     row_fmac<J>(inner, gx, x);
     row_fmac<J>(inner, gz, z);
@@ -643,10 +660,13 @@ template <int GEOM, int MB, int GSRC, int COOP, int TRAJ = 0, int KA = 0>
 DSD void walk_body(const WalkParams &p_arg) {
   const WalkParams &p = fresh_params<KA>(p_arg);
   constexpr bool ROWG = GSRC == 0 && MB >= 16 && GEOM != GEOM_MESH; /* gradient samples through DPP row broadcasts (analytic substrates) */
-  extern __shared__ double lds[];
-  double *log_tab = lds;                           /* 128 doubles                     */
-  double *cos_tab = lds + DS_LOG_TABLE_DOUBLES;    /* 514 doubles                     */
-  double *bounds = cos_tab + DS_COS_TABLE_DOUBLES; /* mesh only                       */
+  /* [r6] the two tables of the random step as STATIC arrays: their LDS addresses are compile-time constants that fold into
+   * the offset field of the reads (behind the dynamic array every table look-up first added the array's base, a
+   * relocation the compiler cannot fold: six vector instructions per time step).  DS_STATIC_LDS_BYTES on the host. */
+  __shared__ __attribute__((aligned(16))) double log_tab[DS_LOG_TABLE_DOUBLES]; /* 128 doubles */
+  __shared__ __attribute__((aligned(16))) double cos_tab[DS_COS_TABLE_DOUBLES]; /* 514 doubles */
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *bounds = lds; /* mesh only */
   int n_bounds = 0;
   if (GEOM == GEOM_MESH) n_bounds = p.mesh.nx + p.mesh.ny + p.mesh.nz + 3;
   double *gt = bounds + ((n_bounds + 1) & ~1);     /* gradient tile, 16-byte aligned  */
