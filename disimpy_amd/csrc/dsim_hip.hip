@@ -2415,6 +2415,7 @@ extern "C" int dsim_run_mesh(dsim_handle h, int64_t max_iter, double epsilon, do
   p.max_iter = max_iter;
   p.eps = epsilon;
   p.perm_prob = perm_prob;
+  p.perm_thresh = ds_perm_threshold(perm_prob);
   p.mesh = mesh_dev(h->mesh);
   return run_impl(h, GEOM_MESH, p, t_begin, t_end);
 }

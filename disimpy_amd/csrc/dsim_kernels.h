@@ -140,6 +140,7 @@ struct WalkParams {
   double R[9], Rinv[9];
   int64_t max_iter;
   double eps, perm_prob;
+  int64_t perm_thresh; /* ds_perm_threshold(perm_prob): the cooperative mesh kernel decides reflection / crossing on the draw's integer bits */
   MeshDev mesh;
   double *traj; /* walk_kernel_coop4_traj: [t - t_begin][3][n], the positions after every time step of the launch */
   /* > 0: WALKER-major instead, [slot][traj_row_steps][x y z 0]: a walker's step is ONE 32-byte store into its own row.

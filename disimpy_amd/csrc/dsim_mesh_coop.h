@@ -85,7 +85,8 @@
  * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
   unsigned long long best_d[64];   /* smallest positive d (bit pattern orders like the value)                 0.5 KB */
-  unsigned best_tri[64];           /* a triangle that attains it (the smallest index among those seen)        0.25 KB */
+  uint2 hit[64];                   /* {a triangle that attains it (the smallest index among those seen), flags: byte 0 = some work of this
+                                    * owner did not fit a queue (redo serially), byte 1 = two different triangles share its smallest d} 0.5 KB */
   uint2 first[64];                 /* every owner's first run {owner | shifts << 6 | (cells - 1) << 24, subvoxel * k^3 + first cell} */
   unsigned more[COOP_RUNQ_CAP - 64]; /* the other runs, by name only: owner | number of the run << 6              1.5 KB */
   int4 plan_a[64];                 /* what the runs of an owner are numbered over (RunPlan): a0, b0, c0, c1 ...          */
@@ -93,14 +94,16 @@ struct CoopWave {
   uint2 items[COOP_ITEM_CAP];      /* items {first record | (count - 1) << 29, owner | shifts << 6} (1c -> 2)  2.5 KB */
   unsigned surv_tri[COOP_SURV_CAP]; /* survivors (2 -> 3): triangle,                                                  */
   unsigned surv_tag[COOP_SURV_CAP]; /*   owner | shifts << 6 (directly behind surv_tri: stage 2 writes both through one pointer) 1.0 KB */
-  unsigned char overflow[64];      /* some work of this owner did not fit a queue: redo serially                     */
-  unsigned char tie[64];           /* two different triangles share this owner's smallest d: the reference's order decides */
   int pad[4];
 #ifdef DSIM_TIMERS
   unsigned long long tacc[16], tlast;
   unsigned long long tpad;
 #endif
 };
+
+#define COOP_BEST_TRI(W, i) ((W)->hit[i].x)
+#define COOP_OVERFLOW(W, i) (reinterpret_cast<unsigned char *>(&(W)->hit[i].y)[0])
+#define COOP_TIE(W, i) (reinterpret_cast<unsigned char *>(&(W)->hit[i].y)[1])
 
 static_assert(offsetof(CoopWave, surv_tag) == offsetof(CoopWave, surv_tri) + COOP_SURV_CAP * sizeof(unsigned),
               "stage 2 writes a survivor's triangle and tag through one pointer");
@@ -403,16 +406,16 @@ DSD void flush_survivors(const MeshDev &ms, const V3 &r0, const V3 &step, CoopWa
   { /* a smaller minimum than at the last flush: what was known about the old one is void */
     const unsigned long long cur = W->best_d[lane];
     if (cur != seen_d) {
-      W->best_tri[lane] = 0xffffffffu;
-      W->tie[lane] = 0;
+      COOP_BEST_TRI(W, lane) = 0xffffffffu;
+      COOP_TIE(W, lane) = 0;
       seen_d = cur;
     }
   }
   wave_sync();
   if (valid && d > 0 && (unsigned long long)__double_as_longlong(d) == W->best_d[owner]) {
     /* pass B: the same triangle again (another cell, another subvoxel or image) is no tie - it IS the winner */
-    const unsigned old = atomicMin(&W->best_tri[owner], tri);
-    if (old != 0xffffffffu && old != tri) W->tie[owner] = 1;
+    const unsigned old = atomicMin(&COOP_BEST_TRI(W, owner), tri);
+    if (old != 0xffffffffu && old != tri) COOP_TIE(W, owner) = 1;
   }
   wave_sync();
   T_MARK(W, lane, 6);
@@ -434,6 +437,13 @@ DSD bool walker_is_clear(const MeshDev &ms, const V3 &r) {
   const int lw = lf >= 2 ? 3 * lf - 5 : 0; /* log2 of the dwords per block */
   const uint32_t w = ms.clear_bits[((size_t)blk << lw) + (bit >> 5)];
   return ((w >> (bit & 31u)) & 1u) == 0u;
+}
+
+/* the one-level table of a run's records: lk > 0 the dense cell table (a slot block for every subvoxel; nullptr when it was not
+ * built), lk == 0 cell_start itself - indexed by the subvoxel, [r6] read through the same paired buffer loads (entries named by
+ * 32-bit byte offsets: fewer than 2^30 subvoxels) */
+DSD const uint32_t *cell_table(const MeshDev &ms) {
+  return ms.lk > 0 ? ms.cell_dense : ((unsigned)(ms.nx * ms.ny * ms.nz) < (1u << 30) ? ms.cell_start : nullptr);
 }
 
 /* ONE pass of the reflect loop of simulations.py:924-997 for the 64 walkers of a wavefront
@@ -467,9 +477,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
   if (wave_ballot(act) == 0ULL) return finished;
   COOP_PRIO_LOOKUPS();
   W->best_d[lane] = 0x7ff0000000000000ULL; /* +inf */
-  W->best_tri[lane] = 0xffffffffu;
-  W->overflow[lane] = 0;
-  W->tie[lane] = 0;
+  W->hit[lane] = make_uint2(0xffffffffu, 0u); /* no triangle, no flag: one 8-byte store */
   T_MARK(W, lane, 1);
 #ifdef DSIM_TIMERS
   if (lane == 0) W->tacc[10] += 1;
@@ -545,10 +553,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const int lk = ms.lk;
     const int lcs = 3 * lk + 2;                 /* log2 of the cell slots per subvoxel, lk > 0 */
     const unsigned cmask = (1u << lcs) - 1u;
-    /* the one-level table of a run's records: lk > 0 the dense cell table (a slot block for every subvoxel), lk == 0 cell_start
-     * itself - indexed by the subvoxel, [r6] read through the same paired buffer loads (entries named by 32-bit byte offsets:
-     * fewer than 2^30 subvoxels) */
-    const uint32_t *const dense = lk > 0 ? ms.cell_dense : ((unsigned)(ms.nx * ms.ny * ms.nz) < (1u << 30) ? ms.cell_start : nullptr);
+    const uint32_t *const dense = cell_table(ms);
     const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.mrec, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t dense_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dense, 0, -1, 0x00020000);
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
@@ -659,8 +664,8 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
           }
           /* the runs of lane 0 alone hold more records than the whole queue: their owners work serially */
           if (lane == 0) {
-            if (ea.x != 0xffffffffu) W->overflow[(int)(ea.x & 63u)] = 1;
-            if (eb.x != 0xffffffffu) W->overflow[(int)(eb.x & 63u)] = 1;
+            if (ea.x != 0xffffffffu) COOP_OVERFLOW(W, (int)(ea.x & 63u)) = 1;
+            if (eb.x != 0xffffffffu) COOP_OVERFLOW(W, (int)(eb.x & 63u)) = 1;
           }
           cur_a = min(64, cur_a + 1);
           cur_b = min(n_extra, cur_b + 1);
@@ -774,7 +779,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
                 W->surv_tri[slot] = q0[u].w;
                 W->surv_tag[slot] = it.y;
               } else
-                W->overflow[owner] = 1;
+                COOP_OVERFLOW(W, owner) = 1;
               slot++;
             }
           }
@@ -797,8 +802,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
      * whether the walker has to go through the pass on its own - queues overflowed, or two triangles at the same distance
      * within the step (the reference's visiting order decides between them) */
     double d = __longlong_as_double((long long)W->best_d[lane]);
-    int tri = (int)W->best_tri[lane];
-    const bool redo = serial | (W->overflow[lane] != 0) | ((d <= step_l) & (W->tie[lane] != 0));
+    const uint2 hv = W->hit[lane]; /* triangle and flags: one 8-byte load */
+    int tri = (int)hv.x;
+    const bool redo = serial | ((hv.y & 0xffu) != 0u) | ((d <= step_l) & ((hv.y & 0xff00u) != 0u));
     if (redo) {
       /* this walker's whole iteration again, by its own lane, exactly as the reference does it */
       STAT_LANE(9);
@@ -816,7 +822,9 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
       finished = true; /* check_intersection = False */
     } else {
       V3 n = load_v3(ms.tri + (int64_t)tri * DS_TRI_STRIDE + 9);
-      const bool reflect = p.perm_prob < rng_uniform_f64(rng);
+      /* perm_prob < u on the integer bits of the draw (ds_perm_threshold): a shift and a comparison instead of two conversions,
+       * a multiplication, an fma and a comparison - the same decision for every draw */
+      const bool reflect = (int64_t)(rng_next(rng) >> 11) > p.perm_thresh;
       if (reflect)
         reflection<!DSIM_DEFER_NORM>(r0, step, d, n, p.eps);
       else

@@ -328,6 +328,7 @@ extern "C" int dsu_mesh_pass(const double *vertices, long long n_vertices, const
   p.max_iter = max_iter;
   p.eps = eps;
   p.perm_prob = perm_prob;
+  p.perm_thresh = ds_perm_threshold(perm_prob);
   p.xcd_run_log2 = 3;
   p.mesh = mesh_dev(dm);
   p.mesh.clear_idx = nullptr;

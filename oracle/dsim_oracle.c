@@ -696,6 +696,9 @@ double dso_u_uniform_f64(dso_state *s) { return uniform_f64(s); }
 float dso_u_logf(float x) { return DSO_LOGF(x); }
 #ifdef DSO_SHARED_MATH
 void dso_u_div3(double *v, double length) { ds_div3(&v[0], &v[1], &v[2], length); }
+/* the product's integer form of `perm_prob < u` (dsim_math.h, ds_perm_threshold), handed out so that tests/test_dsim_math.py
+ * can hold it against the reference's own comparison (simulations.py:988) */
+int64_t dso_u_perm_threshold(double perm_prob) { return ds_perm_threshold(perm_prob); }
 #endif
 double dso_u_cos(double x) { return DSO_COS(x); }
 size_t dso_sizeof_geom(void) { return sizeof(dso_geom); }

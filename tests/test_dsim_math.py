@@ -89,3 +89,25 @@ def test_cos_error_on_every_possible_uniform(oracle_exact):
     oracle_exact.lib.dso_u_cos_sweep(_f32_bits(2.0**-53), _f32_bits(1.0) + 1, a.ctypes.data_as(p), b.ctypes.data_as(p))
     assert 0 < a[0] < 1.2e-16
     assert b[0] < 1.01
+
+
+def test_perm_threshold_is_the_reference_comparison_on_integer_bits(oracle_exact):
+    """ds_perm_threshold (dsim_math.h): `perm_prob < u` of disimpy/simulations.py:988 with u = k * 2^-53, k the upper 53 bits
+    of the draw (numba/cuda/random.py:128-139), decided as k > threshold - for probabilities all over [0, 1], at both ends,
+    outside the range, and for the k around every threshold"""
+    import ctypes as C
+
+    f = oracle_exact.lib.dso_u_perm_threshold
+    f.argtypes, f.restype = [C.c_double], C.c_int64
+    rng = np.random.RandomState(8)
+    probs = np.concatenate([rng.uniform(0, 1, 2000), 10.0 ** rng.uniform(-18, 0, 2000), rng.randint(0, 2**53, 2000) * 2.0**-53,
+                            [0.0, 1.0, 0.5, 2.0**-53, 2.0**-54, 1 - 2.0**-53, 1 + 2.0**-52, 7.0, -0.0, -1e-300, -3.0, np.inf, -np.inf, np.nan, 5e-324]])
+    top = 2**53 - 1
+    for p in probs:
+        t = int(f(float(p)))
+        ks = {0, 1, 2, top, top - 1, 2**52, int(rng.randint(0, 2**53))}
+        if 0 <= t <= top:
+            ks |= {max(0, t - 1), t, min(top, t + 1)}
+        for k in ks:
+            u = float(k) * 2.0**-53  # exact: k < 2^53
+            assert (p < u) == (k > t), (p, k, t)
