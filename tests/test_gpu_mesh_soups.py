@@ -61,6 +61,30 @@ def test_triangle_soup_bit_identical(lib, oracle_exact, case, traversal):  # noq
     assert moved.max() > step_l  # they did walk
 
 
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[7]], ids=lambda c: "soup%d" % c[0])
+def test_two_level_look_up_without_the_dense_cell_table(lib, oracle_exact, case, monkeypatch):  # noqa: F811
+    """The dense cell table (a slot block for every subvoxel) is an optimisation: when it is not built - it would pass
+    DSIM_DENSE_CELLS_MB, or its memory is not to be had (then the allocation error is cleared and the shard goes on,
+    ADVICE round 5) - the cooperative traversal finds a run's records through sv_base -> cell_start.  DSIM_DENSE_CELLS_MB=0
+    takes that path on purpose: every walker bit for bit against the exact oracle, as with the table"""
+    from disimpy_amd import substrates
+
+    monkeypatch.setenv("DSIM_DENSE_CELLS_MB", "0")
+    seed, n_tri, size, voxel, n_sv, step_um, periodic, perm_prob, cells = case
+    assert cells > 1  # meshes with fine cells: without them cell_start is indexed by the subvoxel itself
+    v, f = _soup(seed, n_tri, size, voxel)
+    sub = substrates.mesh(v, f, periodic, n_sv=np.array(n_sv), quiet=True, perm_prob=perm_prob)
+    step_l = step_um * 1e-6
+    n, T, dt = 4096 + 37, 24, 1e-4
+    g = _random_gradient(2, T)
+    pos0 = np.random.RandomState(100 + seed).random_sample((n, 3)) * sub.voxel_size
+    kw = dict(max_iter=1000, epsilon=1e-13, perm_prob=perm_prob)
+    ma = _mesh_arrays(sub)
+    ref = _oracle_run(oracle_exact, MESH, n, g, dt, step_l, pos0, 11 + seed, kw, mesh=ma)
+    gpu = _gpu_run(lib, MESH, n, g, dt, step_l, pos0, 11 + seed, kw, mesh=ma, tuning=dict(mesh_traversal=2, resort_steps=5), chunks=[0, 9, T])
+    _assert_identical(gpu, ref)
+
+
 @pytest.mark.parametrize("intra", [True, False])
 @pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[4], CASES[6], CASES[7], CASES[9]], ids=lambda c: "soup%d" % c[0])
 def test_fill_of_a_triangle_soup_identical_to_oracle(lib, oracle_exact, case, intra):  # noqa: F811
