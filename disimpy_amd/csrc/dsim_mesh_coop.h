@@ -80,7 +80,7 @@
 #define COOP_MAX_RUNS 64  /* per owner and pass */
 #define COOP_NO_SHIFT 0x20820u /* (tag >> 6) & 0x3ffff when all three image numbers are 0 (stored + 32, 6 bits each) */
 
-/* Per-wavefront scratch in LDS (7.4 KB).  The owners' cull boxes and rays are NOT here: they
+/* Per-wavefront scratch in LDS (7.5 KB).  The owners' cull boxes and rays are NOT here: they
  * stay in the owners' registers and the lane that works on an item reads them with ds_bpermute
  * (__shfl), which costs LDS bandwidth but no LDS space. */
 struct CoopWave {
