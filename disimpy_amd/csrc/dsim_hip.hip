@@ -1136,7 +1136,10 @@ extern "C" int dsim_mesh_fine_grid(const double *vertices, int64_t n_vertices, c
         const float b[6] = {q.lo[0], q.lo[1], q.lo[2], q.hi[0], q.hi[1], q.hi[2]}; /* min x y z, max x y z */
         memcpy(rec_box + 6 * r, b, sizeof(b));
       }
-      if (rec_packed) memcpy(rec_packed + 8 * r, &fg.mrec[2 * (size_t)r], 32);
+      if (rec_packed) { /* the record and the plane of its triangle */
+        memcpy(rec_packed + 8 * r, &fg.mrec[(size_t)r], 16);
+        memcpy(rec_packed + 8 * r + 4, &fg.planes[(size_t)q.tri], 16);
+      }
     }
     if (quantum) *quantum = fg.qs;
   }

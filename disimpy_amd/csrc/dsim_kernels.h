@@ -89,9 +89,12 @@ struct MeshDev {
    * with ONE level of look-ups instead of sv_base -> cell_start.  Built on the device from the two compact arrays
    * (expand_cells_kernel); nullptr when the table would exceed DSIM_DENSE_CELLS_MB (the two-level path then) */
   const uint32_t *cell_dense;
-  /* [r5] 32-byte records, two 16-byte loads each (rounds 2-4: 48 bytes, three loads, float32 boxes):
-   *   [0] = {lo_x | lo_y << 16,  lo_z | nhi_x << 16,  nhi_y | nhi_z << 16,  triangle}
-   *   [1] = {nx, ny, nz, c}   float32 supporting plane n.x = c of the triangle
+  /* [r6] 16-byte records, one load each, and the triangle's plane by a second load from a table indexed by the triangle
+   * (round 5: 32-byte records that carried the plane; rounds 2-4: 48 bytes, float32 boxes):
+   *   mrec[r]   = {lo_x | lo_y << 16,  lo_z | nhi_x << 16,  nhi_y | nhi_z << 16,  triangle}
+   *   planes[t] = {nx, ny, nz, c}   float32 supporting plane n.x = c of triangle t - the same in every cell that lists it
+   * (the neuron refined to 50 000 triangles: 1.28 M records = 20 MB + 0.8 MB of planes instead of 41 MB; a wavefront's walkers
+   * share their triangles, so the planes come out of L1 / L2).
    * The box - of the triangle's part inside the cell - in 15-bit fixed point: coordinate x -> x * qs with ONE scale for the
    * three axes, qs = 32767 / (the largest of xs[nx], ys[ny], zs[nz]) - the reference's grids start at 0
    * (substrates.py:506-508), so the voxel maps into [0, 32767]; lo rounded down, hi rounded up and stored as
@@ -103,6 +106,7 @@ struct MeshDev {
    * what passes is a superset of what passed the float32 comparison, looser by up to 2 quanta (6.8 nm on the neuron's
    * 223 um voxel, cells of 0.5 um) per side */
   const ds_uint4 *mrec;
+  const ds_uint4 *planes;
   float qs;
   int lk;
   const double *bounds;    /* xs | ys | zs, (nx+1)+(ny+1)+(nz+1) doubles  */
@@ -435,8 +439,8 @@ DSD void scan_candidates(const MeshDev &ms, int begin, int end, const CullBox &c
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int j = min(i + u, end - 1);
-      q0[u] = ms.mrec[2 * j];
-      q1[u] = ms.mrec[2 * j + 1];
+      q0[u] = ms.mrec[j];
+      q1[u] = ms.planes[q0[u].w];
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {

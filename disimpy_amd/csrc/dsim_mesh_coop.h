@@ -64,7 +64,7 @@
 #define COOP_PRIO_ARITHMETIC() __builtin_amdgcn_s_setprio(0)
 
 #define COOP_ITEM_CAP 320
-/* records per item (stage 2 tests them in one trip).  [r5] 5 of the 32-byte records (40 VGPRs; four 48-byte records took
+/* records per item (stage 2 tests them in one trip).  [r5] 5 records ([r6]: 16 bytes + the 16 bytes of the triangle's plane: 40 VGPRs; four 48-byte records took
  * 44): a pass of the refined neuron then needs 1.92 items per walker instead of 2.31 (the mean run holds 8 records) and
  * its items are two trips of stage 2 more often than three.  Same-box A/B (profiles/history/r05_ab_mesh_kernel_steps.txt): C5b
  * +3.7 % at 1e7 and at 1.25e6 walkers, C4 +0.4 %; 6 records per item need 5 spilled VGPRs at four wavefronts per SIMD and
@@ -555,6 +555,7 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
     const unsigned cmask = (1u << lcs) - 1u;
     const uint32_t *const dense = cell_table(ms);
     const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.mrec, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t plane_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ms.planes, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t dense_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dense, 0, -1, 0x00020000);
     unsigned long long seen_d = 0x7ff0000000000000ULL; /* best_d[lane] at the last flush */
     /* two cursors: over the 64 first-run slots and over the named extra runs behind them.  A trip of stage 1c gives
@@ -701,15 +702,15 @@ DSD bool coop_iteration(V3 &r0, V3 &step, double &step_l, int64_t &iter_idx, boo
         int cnt = (valid && !ABLATE(3) && !ABLATE(4)) ? (int)(it.x >> 29) + 1 : 0;
         asm volatile("" : "+v"(cnt)); /* (opaque: `cnt > u` below stays ONE comparison instead of valid & (count > u)) */
         /* buffer loads: the index as a scalar resource, a record named by its 32-bit byte offset (one shift per record
-         * instead of a 64-bit address in two VGPRs; 29 bits of record number x 32 bytes wrap at 2^32 bytes, hence the 2^27
-         * records upload_mesh admits) */
+         * instead of a 64-bit address in two VGPRs; 28 bits of record number x 16 bytes: the 2^28 records upload_mesh admits).
+         * [r6] The five 16-byte records of the item from one address register at immediate offsets, then - as they
+         * arrive - the planes of the triangles they name from the table by triangle */
         ds_uint4 q0[COOP_ITEM_RECS], q1[COOP_ITEM_RECS];
-        const int rec_off = (ABLATE(4) ? 0 : first_rec) << 5; /* 4: every lane reads the first records of the index */
+        const int rec_off = (ABLATE(4) ? 0 : first_rec) << 4; /* 4: every lane reads the first records of the index */
 #pragma unroll
-        for (int u = 0; u < COOP_ITEM_RECS; u++) { /* one address, ten immediate offsets */
-          q0[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_off + u * 32, 0, 0);
-          q1[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_off + u * 32 + 16, 0, 0);
-        }
+        for (int u = 0; u < COOP_ITEM_RECS; u++) q0[u] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_off + u * 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < COOP_ITEM_RECS; u++) q1[u] = __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, (int)(q0[u].w << 4), 0, 0);
         const int owner = (int)(it.y & 63u);
         /* the owner's segment (plane test: midpoint and half vector as the pairs {m, h} per axis) and its box in the
          * records' fixed point: ten dwords; the float32 box itself is only rebuilt for a periodic image */

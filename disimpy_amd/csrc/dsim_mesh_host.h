@@ -44,7 +44,7 @@ struct DevMesh {
   double *tri = nullptr;
   int2 *sv_range = nullptr;
   int32_t *tri_idx = nullptr;
-  ds_uint4 *mrec = nullptr;
+  ds_uint4 *mrec = nullptr, *planes = nullptr;
   float qs = 0; /* fixed point of the record boxes: x -> x * qs (MeshDev) */
   int32_t *sv_base = nullptr;
   uint32_t *cell_start = nullptr;
@@ -71,6 +71,7 @@ static void free_mesh(DevMesh &m) {
   if (m.sv_range) (void)hipFree(m.sv_range);
   if (m.tri_idx) (void)hipFree(m.tri_idx);
   if (m.mrec) (void)hipFree(m.mrec);
+  if (m.planes) (void)hipFree(m.planes);
   if (m.sv_base) (void)hipFree(m.sv_base);
   if (m.cell_start) (void)hipFree(m.cell_start);
   if (m.cell_dense) (void)hipFree(m.cell_dense);
@@ -352,11 +353,14 @@ static float record_quantum(const double *const b3[3], const int64_t n_sv[3]) {
   return std::isfinite(qs) ? qs : 0.0f; /* 0: every box becomes [0, 0] and nothing is culled by it */
 }
 
-/* 32-byte device records from the float32 ones: lo rounded down, hi rounded up in the EXACT value of x * qs (double
- * arithmetic on the float32 constant; 1e-6 quanta of slack for its own rounding), clamped into [0, 32767] */
-static void pack_records(const std::vector<HostRecord> &recs, float qs, std::vector<uint4> &out) {
-  /* + 8 records of padding: the cooperative traversal loads an item's full width whatever its count (dsim_mesh_coop.h, stage 2) */
-  out.resize((recs.size() + 8) * 2, make_uint4(0u, 0u, 0u, 0u));
+/* [r6] Device records from the float32 ones: 16 bytes per record {box, triangle} - lo rounded down, hi rounded up in the EXACT
+ * value of x * qs (double arithmetic on the float32 constant; 1e-6 quanta of slack for its own rounding), clamped into
+ * [0, 32767] - and, ONCE per triangle, its float32 supporting plane {nx, ny, nz, c} (rounds 2-5 carried the plane in every
+ * record: the same 16 bytes in each of the dozen cells that list a triangle) */
+static void pack_records(const std::vector<HostRecord> &recs, float qs, size_t n_triangles, std::vector<uint4> &out, std::vector<uint4> &planes) {
+  /* + 8 records of padding (they name triangle 0): the cooperative traversal loads an item's full width whatever its count (dsim_mesh_coop.h, stage 2) */
+  out.assign(recs.size() + 8, make_uint4(0u, 0u, 0u, 0u));
+  planes.assign(std::max<size_t>(n_triangles, 1), make_uint4(0u, 0u, 0u, 0u));
   auto q = [&](float x, bool up) -> uint32_t {
     const double v = (double)x * (double)qs;
     double r = up ? std::ceil(v + 1e-6) : std::floor(v - 1e-6);
@@ -371,8 +375,8 @@ static void pack_records(const std::vector<HostRecord> &recs, float qs, std::vec
     uint32_t nb[4];
     memcpy(nb, r.n, 12);
     memcpy(nb + 3, &r.c, 4);
-    out[2 * i] = make_uint4(lx | (ly << 16), lz | (hx << 16), hy | (hz << 16), (uint32_t)r.tri);
-    out[2 * i + 1] = make_uint4(nb[0], nb[1], nb[2], nb[3]);
+    out[i] = make_uint4(lx | (ly << 16), lz | (hx << 16), hy | (hz << 16), (uint32_t)r.tri);
+    planes[(size_t)r.tri] = make_uint4(nb[0], nb[1], nb[2], nb[3]); /* the same for every record of the triangle */
   }
 }
 
@@ -382,7 +386,7 @@ struct HostFineGrid {
   std::vector<int32_t> sv_base;
   std::vector<uint32_t> cell_start;
   std::vector<HostRecord> recs;
-  std::vector<uint4> mrec; /* recs as the device gets them */
+  std::vector<uint4> mrec, planes; /* recs as the device gets them: 16-byte records and the planes by triangle */
   float qs = 0;
 };
 
@@ -393,7 +397,7 @@ struct HostMesh {
   std::vector<int2> ranges;
   std::vector<int32_t> refs, sv_base, cidx;
   std::vector<uint32_t> cell_start, recs_before, cbits;
-  std::vector<uint4> packed;
+  std::vector<uint4> packed, planes; /* 16-byte records (+ padding), float32 planes by triangle */
   std::vector<double> bounds;
   int lk = 0, clear_lf = 0;
   double clear_frac = 0, step_l = 0;
@@ -481,8 +485,8 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
    * cell around it).  Boxes wider than two units take cells i, i + 2, ...  The price is memory: (2k)^2 k cell slots per
    * non-empty subvoxel (slot 2k - 1 of an axis is never used: shifts instead of multiplications) and about 2.5 times
    * the records.  Along z the cells are disjoint, stored fastest with their records back to back, so a run of cells
-   * along z is ONE contiguous range of records.  Records (packed to 32 bytes by pack_records) {AABB of the triangle's part inside the cell,
-   * supporting plane in float32, triangle, position in the reference's list}:
+   * along z is ONE contiguous range of records.  Records (packed to 16 bytes by pack_records, the plane kept once per triangle)
+   * {AABB of the triangle's part inside the cell, supporting plane in float32, triangle, position in the reference's list}:
    *     sv_base[s]           first cell of subvoxel s in cell_start, -1 for an empty subvoxel
    *                          (lk == 0: not used, cell_start is indexed by s itself, nothing overlaps)
    *     cell                 sv_base[s] + ((i * 2k + j) * k + c)
@@ -657,7 +661,7 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
       }
       mrec.insert(mrec.end(), bu.recs.begin(), bu.recs.end());
     }
-    if (mrec.size() + 8 >= 0x08000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* the cooperative traversal names a record by a 32-bit byte offset (32 bytes each) */
+    if (mrec.size() + 8 >= 0x10000000ull) return fail(DSIM_ERR_INVALID, "mesh: too many fine-grid records"); /* the cooperative traversal names a record by a 32-bit byte offset (16 bytes each) */
     cell_start.push_back((uint32_t)mrec.size()); /* end of the last cell */
     if (lk > 0) recs_before[(size_t)n_sub] = (uint32_t)mrec.size();
   }
@@ -667,13 +671,14 @@ static int upload_mesh(DevMesh &dm, hipStream_t stream, const double *vertices, 
     qs = record_quantum(b3, n_sv);
   }
   std::vector<uint4> &packed = hm.packed;
-  pack_records(mrec, qs, packed);
+  pack_records(mrec, qs, (size_t)n_faces, packed, hm.planes);
   if (host_only) { /* no device involved */
     host_only->lk = lk;
     host_only->sv_base.swap(sv_base);
     host_only->cell_start.swap(cell_start);
     host_only->recs.swap(mrec);
     host_only->mrec.swap(packed);
+    host_only->planes.swap(hm.planes);
     host_only->qs = qs;
     return DSIM_OK;
   }
@@ -724,6 +729,8 @@ static int upload_mesh_host(DevMesh &dm, hipStream_t stream, const HostMesh &hm)
   HIP_TRY(hipMalloc(&dm.sv_range, hm.ranges.size() * sizeof(int2)));
   HIP_TRY(hipMalloc(&dm.tri_idx, hm.refs.size() * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&dm.mrec, hm.packed.size() * sizeof(uint4)));
+  HIP_TRY(hipMalloc(&dm.planes, hm.planes.size() * sizeof(uint4)));
+  HIP_TRY(hipMemcpyAsync(dm.planes, hm.planes.data(), hm.planes.size() * sizeof(uint4), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMalloc(&dm.sv_base, hm.sv_base.size() * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&dm.cell_start, hm.cell_start.size() * sizeof(uint32_t)));
   HIP_TRY(hipMemcpyAsync(dm.mrec, hm.packed.data(), hm.packed.size() * sizeof(uint4), hipMemcpyHostToDevice, stream));
@@ -783,6 +790,7 @@ static MeshDev mesh_dev(const DevMesh &dm) {
   m.sv_range = dm.sv_range;
   m.tri_idx = dm.tri_idx;
   m.mrec = dm.mrec;
+  m.planes = dm.planes;
   m.qs = dm.qs;
   m.sv_base = dm.sv_base;
   m.cell_start = dm.cell_start;

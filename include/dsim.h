@@ -24,7 +24,7 @@
  *     on every axis (substrates.py:506-508): any other boundaries handed in here are walked by the per-lane
  *     traversal (mesh_traversal 1; same results, checked against the boundary values themselves), as is a mesh of 2^25
  *     triangles or more (the cooperative traversal names a triangle by a 32-bit byte offset); the fine grid built on top of
- *     the subvoxel lists may hold at most 2^27 records (32 bytes each, named by byte offsets: dsim_set_mesh fails beyond).  A walker whose
+ *     the subvoxel lists may hold at most 2^28 records (16 bytes each, named by byte offsets: dsim_set_mesh fails beyond).  A walker whose
  *     segment reaches more than 31 periodic images away from the voxel, spans more than 64 runs of fine cells or meets
  *     two different triangles at bit-equal distances is redone by its own lane in the reference's order (same
  *     results); the LDS request (subvoxel boundaries + tables + work queues) must stay below 160 KB,
@@ -282,8 +282,9 @@ int dsim_mesh_clearance_map(const double *vertices, int64_t n_vertices, const in
  * (sv_base[s] = -1: empty), slot ((i * 2k + j) * k + c) = the cell that starts at unit i along x, unit j along y, z cell c
  * (the slots with i or j = 2k - 1 stay empty).  The records of slot q are [cell_start[q], cell_start[q + 1]).  Per record
  * the triangle, its position in the reference's triangle_indices and the float32 box {min x, y, z, max x, y, z} of the
- * triangle's part inside the cell; rec_packed (8 dwords per record, may be NULL): the 32-byte record as the kernels read
- * it - {lo_x | lo_y << 16, lo_z | nhi_x << 16, nhi_y | nhi_z << 16, triangle, plane nx, ny, nz, c as float32 bits}, the box
+ * triangle's part inside the cell; rec_packed (8 dwords per record, may be NULL): the 16-byte record as the kernels read
+ * it followed by the plane of its triangle, which the kernels keep once per triangle -
+ * {lo_x | lo_y << 16, lo_z | nhi_x << 16, nhi_y | nhi_z << 16, triangle, plane nx, ny, nz, c as float32 bits}, the box
  * in 15-bit fixed point x -> x * *quantum (one float, may be NULL), lo rounded down, hi rounded up and stored as
  * nhi = 32767 - hi.  Exported so that the completeness of the grid can be tested without a GPU
  * (tests/test_fine_grid.py).  Call once with cell_start == NULL for the sizes, then with buffers of *n_cells + 1 and

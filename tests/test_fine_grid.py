@@ -110,7 +110,8 @@ def test_fine_grid_is_complete(lib, name, sub, step_l):
 
 @pytest.mark.parametrize("name,sub,step_l", list(_substrates()), ids=lambda v: v if isinstance(v, str) else "")
 def test_packed_records_hold_their_float32_boxes(lib, name, sub, step_l):
-    """The 32-byte records the kernels read (MeshDev::mrec, dsim_kernels.h): the fixed-point box is the float32 box
+    """The records the kernels read (MeshDev::mrec - 16 bytes: box and triangle - and MeshDev::planes, the plane by the
+    triangle; dsim_mesh_fine_grid hands out both per record): the fixed-point box is the float32 box
     rounded OUTWARDS (never tighter, at most two quanta wider), so whatever overlapped the float32 box overlaps it."""
     fg = lib.mesh_fine_grid(sub.vertices, sub.faces, sub.xs, sub.ys, sub.zs, sub.n_sv, sub.subvoxel_indices, sub.triangle_indices, step_l)
     pk, box, qs = fg["packed"], fg["box"].astype(np.float64), np.float64(np.float32(fg["quantum"]))
