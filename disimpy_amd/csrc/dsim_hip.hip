@@ -550,12 +550,14 @@ extern "C" int dsim_set_positions(dsim_handle h, const double *pos) {
 
 /* Estimated relative cost of a walker-step at the walker's position in a mesh: 1 + c x (records of the fine cell the
  * position lies in, at most 40).  The records are what a pass of the traversal has to test; a walker in an empty
- * cell - the inside of a soma - finishes its steps in one cheap pass.  c = 0.065 from the measured rates of the eight
- * equal-count parts of the refined neuron (1.43e10 in the dendrites, 2.05e10 in the soma) and of the parts cut with
- * c = 0.06 (profiles/history/r05_spatial_parts.txt); DSIM_COST_PER_RECORD overrides it in tuning runs.  Only the CUT depends on
- * it, never a result. */
+ * cell - the inside of a soma - finishes its steps in one cheap pass.  c from the measured rates of the eight parts of the
+ * refined neuron: 0.065 in round 5 (1.43e10 in the dendrites, 2.05e10 in the soma; profiles/history/r05_spatial_parts.txt);
+ * [r6] 0.056 - the traversal has become cheaper per record since (1.55e10 / 2.25e10): with 0.065 the soma part was the
+ * longest of the eight (0.731 s per pass against a mean of 0.690), with 0.055-0.058 the longest is 0.710 s; a lower cap than
+ * 40 records only does worse (profiles/history/r06_spatial_cut_cost_weight.txt).  DSIM_COST_PER_RECORD overrides it in
+ * tuning runs.  Only the CUT depends on it, never a result. */
 static void mesh_walker_cost(const HostMesh &hm, const double *pos, int64_t n, double *w) {
-  double c = 0.065;
+  double c = 0.056;
   if (const char *e = getenv("DSIM_COST_PER_RECORD")) c = atof(e);
   const int lk = hm.lk, k = 1 << lk, ku = lk > 0 ? 2 * k : 1;
   const int per[3] = {ku, ku, k};

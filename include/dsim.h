@@ -54,7 +54,7 @@
  * kernel for a same-box A/B; every symbol of this header must be there, or loading fails - unless DSIM_LIB_OLD_ABI=1
  * says that the build is an OLDER one kept for such a comparison: entry points it lacks raise when they are called.
  * Two more switches belong to this round: DSIM_DENSE_CELLS_MB (cap of the one-level cell table of a mesh, default 4096;
- * 0 = two-level look-ups) and DSIM_COST_PER_RECORD (weight of the spatial cut's cost model, default 0.065).
+ * 0 = two-level look-ups) and DSIM_COST_PER_RECORD (weight of the spatial cut's cost model, default 0.056).
  */
 #ifndef DSIM_H
 #define DSIM_H
@@ -129,7 +129,7 @@ int dsim_set_positions(dsim_handle h, const double *positions_aos);
  * SPACE: the walkers are ordered along the Morton curve of the positions and shard k takes the k-th stretch of that
  * order, so that every GPU works in its own part of a mesh substrate instead of at 1/G of the walker density all over
  * it.  When dsim_set_mesh was called BEFORE, the stretches are of equal estimated cost, not of equal counts (a
- * walker's cost: 1 + 0.065 x the records of the fine cell it starts in - walkers inside a soma are cheap, those in thin
+ * walker's cost: 1 + 0.056 x the records of the fine cell it starts in - walkers inside a soma are cheap, those in thin
  * dendrites dear, and the job ends with its slowest shard); the shards are then created again with their new sizes.
  * The reference has no counterpart (simulations.py:1051 is one GPU).  Walker i keeps RNG state i and position i,
  * host arrays stay in walker order, the exact signal sums do not depend on the cut: every output is the bytes of the
@@ -146,7 +146,7 @@ int dsim_partition_walkers(const double *positions_aos, int64_t n_walkers, int32
                            int64_t *part_start);
 
 /* The weights dsim_partition_by_position uses on a mesh (host only; the arguments of dsim_set_mesh plus the step
- * length the handle was created with): out_cost[i] = 1 + 0.065 x min(40, records of the fine cell of positions[i]). */
+ * length the handle was created with): out_cost[i] = 1 + 0.056 x min(40, records of the fine cell of positions[i]). */
 int dsim_mesh_walker_cost(const double *vertices, int64_t n_vertices, const int64_t *faces, int64_t n_faces, const double *xs,
                           const double *ys, const double *zs, const int64_t n_sv[3], const int64_t *subvoxel_indices,
                           const int64_t *triangle_indices, int64_t n_refs, double step_l, const double *positions_aos,
